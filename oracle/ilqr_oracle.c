@@ -1,0 +1,883 @@
+/*
+ * ilqr_oracle.c -- CPU restatement of the idiap/ilqr_planner hot path (see ilqr_oracle.h).
+ * TEST INFRASTRUCTURE ONLY: never linked into, imported by or called from the product.
+ *
+ * Reference paths are relative to /root/reference/ilqr_planner/ilqr_planner.
+ * All matrices are row-major.  Quirks of the reference are reproduced on purpose.
+ */
+#include "ilqr_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+/* ------------------------------------------------------------------ small dense helpers */
+
+/* C(m x n) = A(m x k) * B(k x n) */
+static void mm(double* C, const double* A, const double* B, int m, int k, int n) {
+    for (int i = 0; i < m; i++)
+        for (int j = 0; j < n; j++) {
+            double s = 0;
+            for (int l = 0; l < k; l++) s += A[i * k + l] * B[l * n + j];
+            C[i * n + j] = s;
+        }
+}
+/* C(m x n) = A^T * B, A is (k x m), B is (k x n) */
+static void mtm(double* C, const double* A, const double* B, int k, int m, int n) {
+    for (int i = 0; i < m; i++)
+        for (int j = 0; j < n; j++) {
+            double s = 0;
+            for (int l = 0; l < k; l++) s += A[l * m + i] * B[l * n + j];
+            C[i * n + j] = s;
+        }
+}
+static double dot(const double* a, const double* b, int n) {
+    double s = 0;
+    for (int i = 0; i < n; i++) s += a[i] * b[i];
+    return s;
+}
+static double norm(const double* a, int n) { return sqrt(dot(a, a, n)); }
+/* Eigen DenseBase::isZero(prec = 1e-12): every |coeff| <= prec */
+static int is_zero(const double* a, int n) {
+    for (int i = 0; i < n; i++)
+        if (!(fabs(a[i]) <= 1e-12)) return 0;
+    return 1;
+}
+
+/* Eigen MatrixXd::inverse() on a dynamic-size matrix = PartialPivLU, then solve against identity. */
+int orc_inverse(int n, const double* A, double* Ainv) {
+    double* lu = (double*)malloc(sizeof(double) * n * n);
+    int* piv = (int*)malloc(sizeof(int) * n);
+    memcpy(lu, A, sizeof(double) * n * n);
+    for (int i = 0; i < n; i++) piv[i] = i;
+    int rc = 0;
+    for (int k = 0; k < n; k++) {
+        int r = k;
+        double best = fabs(lu[k * n + k]);
+        for (int i = k + 1; i < n; i++) {
+            double v = fabs(lu[i * n + k]);
+            if (v > best) { best = v; r = i; }
+        }
+        if (r != k) {
+            for (int j = 0; j < n; j++) { double t = lu[k * n + j]; lu[k * n + j] = lu[r * n + j]; lu[r * n + j] = t; }
+            int t = piv[k]; piv[k] = piv[r]; piv[r] = t;
+        }
+        double pv = lu[k * n + k];
+        if (pv == 0.0) rc = 1;
+        for (int i = k + 1; i < n; i++) {
+            lu[i * n + k] /= pv;
+            double f = lu[i * n + k];
+            for (int j = k + 1; j < n; j++) lu[i * n + j] -= f * lu[k * n + j];
+        }
+    }
+    for (int c = 0; c < n; c++) {
+        /* solve L U x = P e_c */
+        double* x = Ainv; /* column c written strided */
+        for (int i = 0; i < n; i++) {
+            double s = (piv[i] == c) ? 1.0 : 0.0;
+            for (int j = 0; j < i; j++) s -= lu[i * n + j] * x[j * n + c];
+            x[i * n + c] = s;
+        }
+        for (int i = n - 1; i >= 0; i--) {
+            double s = x[i * n + c];
+            for (int j = i + 1; j < n; j++) s -= lu[i * n + j] * x[j * n + c];
+            x[i * n + c] = s / lu[i * n + i];
+        }
+    }
+    free(lu);
+    free(piv);
+    return rc;
+}
+
+/* ------------------------------------------------------------------ Sd manifold utils (utils/sd.h) */
+
+void orc_sd_H(const double q[4], double H[12]) { /* sd.h:23-27 dQuatToDxJac */
+    H[0] = -q[1]; H[1] = q[0];  H[2] = -q[3];  H[3] = q[2];
+    H[4] = -q[2]; H[5] = q[3];  H[6] = q[0];   H[7] = -q[1];
+    H[8] = -q[3]; H[9] = -q[2]; H[10] = q[1];  H[11] = q[0];
+}
+
+double orc_sd_distance(const double x[4], const double y[4]) { /* sd.h:48-62 */
+    double dist = dot(x, y, 4);
+    if (dist > 1) dist = 1;
+    else if (dist < -1) dist = -1;
+    double ac = acos(dist);
+    if (dist < 0) ac -= M_PI;
+    return ac;
+}
+
+void orc_sd_logmap(const double base_in[4], const double y_in[4], double out[4]) { /* sd.h:67-82 */
+    if (is_zero(base_in, 4) || is_zero(y_in, 4)) { memset(out, 0, 4 * sizeof(double)); return; }
+    double b[4], y[4], tmp[4];
+    double nb = norm(base_in, 4), ny = norm(y_in, 4);
+    for (int i = 0; i < 4; i++) { b[i] = base_in[i] / nb; y[i] = y_in[i] / ny; }
+    double by = dot(b, y, 4);
+    for (int i = 0; i < 4; i++) tmp[i] = y[i] - by * b[i];
+    double nt = norm(tmp, 4);
+    if (nt == 0) { memset(out, 0, 4 * sizeof(double)); return; }
+    double d = orc_sd_distance(b, y);
+    for (int i = 0; i < 4; i++) out[i] = d * tmp[i] / nt;
+}
+
+void orc_sd_expmap(const double base_in[4], const double u[4], double out[4]) { /* sd.h:32-43 */
+    double b[4];
+    double nb = norm(base_in, 4);
+    for (int i = 0; i < 4; i++) b[i] = base_in[i] / nb;
+    double nu = norm(u, 4);
+    if (nu == 0) { memcpy(out, b, sizeof(b)); return; }
+    double r[4];
+    for (int i = 0; i < 4; i++) r[i] = b[i] * cos(nu) + u[i] / nu * sin(nu);
+    double nr = norm(r, 4);
+    for (int i = 0; i < 4; i++) out[i] = r[i] / nr;
+}
+
+void orc_sd_transport(const double v[4], const double b1[4], const double b2[4], double out[4]) { /* sd.h:87-99 */
+    if (is_zero(b1, 4) || is_zero(b2, 4)) { memcpy(out, v, 4 * sizeof(double)); return; }
+    double dsq = pow(orc_sd_distance(b1, b2), 2);
+    if (dsq == 0) { memcpy(out, v, 4 * sizeof(double)); return; }
+    double l12[4], l21[4];
+    orc_sd_logmap(b1, b2, l12);
+    orc_sd_logmap(b2, b1, l21);
+    double f = dot(l12, v, 4) / dsq;
+    for (int i = 0; i < 4; i++) out[i] = v[i] - f * (l12[i] + l21[i]);
+}
+
+/* ------------------------------------------------------------------ FK + geometric Jacobian */
+
+static void rot_axis(const double a[3], double th, double R[9]) { /* KDL Rotation::Rot2 (Rodrigues) */
+    double ct = cos(th), st = sin(th), vt = 1 - ct;
+    double x = a[0], y = a[1], z = a[2];
+    R[0] = ct + vt * x * x;     R[1] = -z * st + vt * x * y; R[2] = y * st + vt * x * z;
+    R[3] = z * st + vt * x * y; R[4] = ct + vt * y * y;      R[5] = -x * st + vt * y * z;
+    R[6] = -y * st + vt * x * z; R[7] = x * st + vt * y * z; R[8] = ct + vt * z * z;
+}
+
+/* KDL Rotation::GetQuaternion (orocos_kdl frames.cpp; un-vendored dependency, version unpinned,
+ * restated from the published algorithm; pinned by the negative-w FK literal of POS_ORN_MULTI_SYS.ipynb
+ * cell 8).  Output order (w,x,y,z) as KDLRobot.cpp:103 stores it. */
+static void kdl_quat(const double R[9], double q[4]) {
+    double tr = R[0] + R[4] + R[8];
+    double w, x, y, z;
+    if (tr > 1e-12) {
+        double s = 0.5 / sqrt(tr + 1.0);
+        w = 0.25 / s;
+        x = (R[7] - R[5]) * s;
+        y = (R[2] - R[6]) * s;
+        z = (R[3] - R[1]) * s;
+    } else if (R[0] > R[4] && R[0] > R[8]) {
+        double s = 2.0 * sqrt(1.0 + R[0] - R[4] - R[8]);
+        w = (R[7] - R[5]) / s;
+        x = 0.25 * s;
+        y = (R[1] + R[3]) / s;
+        z = (R[2] + R[6]) / s;
+    } else if (R[4] > R[8]) {
+        double s = 2.0 * sqrt(1.0 + R[4] - R[0] - R[8]);
+        w = (R[2] - R[6]) / s;
+        x = (R[1] + R[3]) / s;
+        y = 0.25 * s;
+        z = (R[5] + R[7]) / s;
+    } else {
+        double s = 2.0 * sqrt(1.0 + R[8] - R[0] - R[4]);
+        w = (R[3] - R[1]) / s;
+        x = (R[2] + R[6]) / s;
+        y = (R[5] + R[7]) / s;
+        z = 0.25 * s;
+    }
+    q[0] = w; q[1] = x; q[2] = y; q[3] = z;
+}
+
+/* src/sim/KDLRobot.cpp:83-115: JntToJac + JntToCart + GetQuaternion, dx = Jt dq, w = Jr dq.
+ * (dJac, :112, is never read by any System and is not restated.) */
+void orc_fk(const orc_chain* c, const double* q, const double* dq,
+            double p[3], double quat[4], double J[6 * ORC_MAX_DOF], double dx[3], double w[3]) {
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pos[3] = {0, 0, 0};
+    double org[ORC_MAX_DOF][3], ax[ORC_MAX_DOF][3];
+    int dof = c->dof;
+    for (int s = 0; s < c->n_seg; s++) {
+        double t[3], Rn[9];
+        for (int i = 0; i < 3; i++) t[i] = R[3 * i] * c->seg_xyz[s][0] + R[3 * i + 1] * c->seg_xyz[s][1] + R[3 * i + 2] * c->seg_xyz[s][2];
+        for (int i = 0; i < 3; i++) pos[i] += t[i];
+        mm(Rn, R, c->seg_R[s], 3, 3, 3);
+        memcpy(R, Rn, sizeof(R));
+        int j = c->seg_joint[s];
+        if (j >= 0) {
+            double Rq[9];
+            for (int i = 0; i < 3; i++) {
+                org[j][i] = pos[i];
+                ax[j][i] = R[3 * i] * c->seg_axis[s][0] + R[3 * i + 1] * c->seg_axis[s][1] + R[3 * i + 2] * c->seg_axis[s][2];
+            }
+            rot_axis(c->seg_axis[s], q[j], Rq);
+            mm(Rn, R, Rq, 3, 3, 3);
+            memcpy(R, Rn, sizeof(R));
+        }
+    }
+    for (int i = 0; i < 3; i++) p[i] = pos[i];
+    kdl_quat(R, quat);
+    for (int j = 0; j < dof; j++) {
+        double r[3] = {pos[0] - org[j][0], pos[1] - org[j][1], pos[2] - org[j][2]};
+        const double* z = ax[j];
+        J[0 * dof + j] = z[1] * r[2] - z[2] * r[1];
+        J[1 * dof + j] = z[2] * r[0] - z[0] * r[2];
+        J[2 * dof + j] = z[0] * r[1] - z[1] * r[0];
+        J[3 * dof + j] = z[0];
+        J[4 * dof + j] = z[1];
+        J[5 * dof + j] = z[2];
+    }
+    for (int i = 0; i < 3; i++) {
+        dx[i] = 0;
+        w[i] = 0;
+        if (dq)
+            for (int j = 0; j < dof; j++) {
+                dx[i] += J[i * dof + j] * dq[j];
+                w[i] += J[(3 + i) * dof + j] * dq[j];
+            }
+    }
+}
+
+/* ------------------------------------------------------------------ System */
+
+void orc_system_finalize(orc_system* s) {
+    s->dof = s->chain.dof;
+    int tm = (s->kind == ORC_SYS_POS_ORN_TIME) ? 1 : 0;
+    s->n_x = s->nb_deriv * s->dof + tm;  /* PosOrnPlannerSys.cpp:74 / PosOrnTimePlannerSys.cpp:67 */
+    s->n_u = s->dof + tm;                /* :75 / :68 */
+    s->n_f = 7 * s->nb_deriv + tm;       /* :76 / :69 */
+    s->n_Q = s->n_f - s->nb_deriv;       /* :77 / :70 */
+}
+
+/* getFxJac(xk): System.cpp:163-179 + PosOrnPlannerSys.cpp:80-102 ; PosOrnTimePlannerSys.cpp:85-137.
+ * fx = [p; quat (; dp; dquat) (; t)], J = Jac | blkdiag(Jac,Jac) | bordered with 1 for the time state. */
+void orc_get_fx_jac(const orc_system* s, const double* x, double* fx, double* J) {
+    int dof = s->dof, nd = s->nb_deriv, tm = (s->kind == ORC_SYS_POS_ORN_TIME);
+    double p[3], quat[4], Jac[6 * ORC_MAX_DOF], dx[3], w[3], dq0[ORC_MAX_DOF] = {0};
+    const double* dq = (nd == 2) ? x + dof : dq0;
+    orc_fk(&s->chain, x, dq, p, quat, Jac, dx, w);
+    if (fx) {
+        memset(fx, 0, sizeof(double) * s->n_f);
+        memcpy(fx, p, 3 * sizeof(double));
+        memcpy(fx + 3, quat, 4 * sizeof(double));
+        if (nd == 2) {
+            double H[12];
+            orc_sd_H(quat, H);
+            memcpy(fx + 7, dx, 3 * sizeof(double));
+            for (int i = 0; i < 4; i++) /* SimulationInterface.cpp:69-73: .5 * H(quat)^T w */
+                fx[10 + i] = .5 * (H[i] * w[0] + H[4 + i] * w[1] + H[8 + i] * w[2]);
+        }
+        if (tm) fx[s->n_f - 1] = x[s->n_x - 1];
+    }
+    if (J) {
+        int nx = s->n_x;
+        memset(J, 0, sizeof(double) * s->n_Q * nx);
+        for (int r = 0; r < 6; r++)
+            for (int c = 0; c < dof; c++) {
+                J[r * nx + c] = Jac[r * dof + c];
+                if (nd == 2) J[(6 + r) * nx + dof + c] = Jac[r * dof + c];
+            }
+        if (tm) J[(s->n_Q - 1) * nx + nx - 1] = 1;
+    }
+}
+
+/* PosOrnKeypoint::diff (PosOrnKeypoint.cpp:24-45), SpacetimeKeypoint::diff (SpacetimeKeypoint.cpp:19-25) */
+void orc_kp_diff(const orc_system* s, const orc_keypoint* kp, const double* fx, double* e) {
+    int nd = s->nb_deriv, tm = (s->kind == ORC_SYS_POS_ORN_TIME);
+    int nst = 7 * nd;
+    memset(e, 0, sizeof(double) * s->n_Q);
+    if (!is_zero(fx, nst)) { /* :29 */
+        double lm[4], H[12];
+        orc_sd_H(kp->orn, H);
+        for (int i = 0; i < 3; i++) e[i] = kp->pos[i] - fx[i];
+        orc_sd_logmap(kp->orn, fx + 3, lm);
+        for (int i = 0; i < 3; i++) e[3 + i] = -2 * dot(H + 4 * i, lm, 4);
+        if (nd == 2) {
+            double tr[4], dv[4];
+            for (int i = 0; i < 3; i++) e[6 + i] = kp->dpos[i] - fx[7 + i];
+            orc_sd_transport(fx + 10, fx + 3, kp->orn, tr);
+            for (int i = 0; i < 4; i++) dv[i] = kp->dorn[i] - tr[i];
+            for (int i = 0; i < 3; i++) e[9 + i] = -2 * dot(H + 4 * i, dv, 4);
+        }
+    }
+    if (tm) e[s->n_Q - 1] = kp->ctime - fx[s->n_f - 1];
+}
+
+static const orc_keypoint* find_kp(const orc_system* s, int k) { /* System.cpp:96-101; later duplicates win in the map */
+    const orc_keypoint* r = NULL;
+    for (int i = 0; i < s->n_kp; i++)
+        if (s->kp[i].timestep == k) r = &s->kp[i];
+    return r;
+}
+
+/* inspectJointLimit, System.cpp:121-142: returns diag(L) and q */
+static void limits(const orc_system* s, const double* x, double* Ld, double* q) {
+    for (int i = 0; i < s->n_x; i++) { Ld[i] = 0; q[i] = 0; }
+    if (!s->limits_set) return;
+    for (int i = 0; i < s->n_x; i++) {
+        if (s->limit_weight[i] != 0) {
+            if (x[i] > s->state_max[i]) { q[i] = s->state_max[i] - x[i]; Ld[i] = s->penalty; }
+            else if (x[i] < s->state_min[i]) { q[i] = s->state_min[i] - x[i]; Ld[i] = s->penalty; }
+        }
+    }
+}
+
+/* System::cost, System.cpp:213-234 (control cost only at keypoint steps: quirk D-2) */
+double orc_cost(const orc_system* s, const double* x, const double* u, int k) {
+    double c = 0;
+    const orc_keypoint* kp = find_kp(s, k);
+    if (kp) {
+        double fx[ORC_MAX_NF], e[ORC_MAX_NQ], Qe[ORC_MAX_NQ];
+        orc_get_fx_jac(s, x, fx, NULL);
+        orc_kp_diff(s, kp, fx, e);
+        int nq = s->n_Q;
+        for (int i = 0; i < nq; i++) Qe[i] = dot(kp->Q + i * nq, e, nq);
+        double ru = 0;
+        for (int i = 0; i < s->n_u; i++) ru += u[i] * s->R_diag[i] * u[i];
+        c += dot(e, Qe, nq) + ru;
+    }
+    if (s->limits_set) {
+        double Ld[ORC_MAX_NX], q[ORC_MAX_NX], a = 0;
+        limits(s, x, Ld, q);
+        for (int i = 0; i < s->n_x; i++) a += q[i] * Ld[i] * q[i];
+        c += a;
+    }
+    return c;
+}
+
+/* System::cost_x, System.cpp:248-272:  -J^T Q e - L^T q */
+void orc_cost_x(const orc_system* s, const double* x, int k, double* lx) {
+    int nx = s->n_x, nq = s->n_Q;
+    memset(lx, 0, sizeof(double) * nx);
+    const orc_keypoint* kp = find_kp(s, k);
+    if (kp) {
+        double fx[ORC_MAX_NF], J[ORC_MAX_NQ * ORC_MAX_NX], e[ORC_MAX_NQ], Qe[ORC_MAX_NQ];
+        orc_get_fx_jac(s, x, fx, J);
+        orc_kp_diff(s, kp, fx, e);
+        for (int i = 0; i < nq; i++) Qe[i] = dot(kp->Q + i * nq, e, nq);
+        for (int c = 0; c < nx; c++) {
+            double a = 0;
+            for (int r = 0; r < nq; r++) a += J[r * nx + c] * Qe[r];
+            lx[c] += -1 * a;
+        }
+    }
+    if (s->limits_set) {
+        double Ld[ORC_MAX_NX], q[ORC_MAX_NX];
+        limits(s, x, Ld, q);
+        for (int i = 0; i < nx; i++) lx[i] += -Ld[i] * q[i];
+    }
+}
+
+/* System::cost_xx, System.cpp:286-308:  J^T Q J + L^T L */
+void orc_cost_xx(const orc_system* s, const double* x, int k, double* lxx) {
+    int nx = s->n_x, nq = s->n_Q;
+    memset(lxx, 0, sizeof(double) * nx * nx);
+    const orc_keypoint* kp = find_kp(s, k);
+    if (kp) {
+        double J[ORC_MAX_NQ * ORC_MAX_NX], JtQ[ORC_MAX_NX * ORC_MAX_NQ], JtQJ[ORC_MAX_NX * ORC_MAX_NX];
+        orc_get_fx_jac(s, x, NULL, J);
+        mtm(JtQ, J, kp->Q, nq, nx, nq);
+        mm(JtQJ, JtQ, J, nx, nq, nx);
+        for (int i = 0; i < nx * nx; i++) lxx[i] += JtQJ[i];
+    }
+    if (s->limits_set) {
+        double Ld[ORC_MAX_NX], q[ORC_MAX_NX];
+        limits(s, x, Ld, q);
+        for (int i = 0; i < nx; i++) lxx[i * nx + i] += Ld[i] * Ld[i];
+    }
+}
+
+/* forwardPass: PosOrnPlannerSys.cpp:114-138, PosOrnTimePlannerSys.cpp:149-184, with the integrator of
+ * SimulationInterface.cpp:19-31.  Functional form of the stateful simulator (the solvers always call it
+ * as reset(); step; step; ... so x is the simulator's own state: quirk D-7). */
+void orc_step(const orc_system* s, const double* x, const double* u,
+              double* x_next, double* fx_next, double* A, double* B, double* J) {
+    int dof = s->dof, nd = s->nb_deriv, nx = s->n_x, nu = s->n_u, tm = (s->kind == ORC_SYS_POS_ORN_TIME);
+    double xn[ORC_MAX_NX];
+    double dtSqrt = tm ? u[nu - 1] : 0.0;
+    double dt = tm ? dtSqrt * dtSqrt : s->dt;
+    if (nd == 1) { /* sendVel: dq = u; q += dt*dq + dt*dt/2*0 */
+        for (int i = 0; i < dof; i++) xn[i] = x[i] + (dt * u[i] + dt * dt / 2 * 0.0);
+    } else { /* sendAcc */
+        for (int i = 0; i < dof; i++) {
+            xn[i] = x[i] + (dt * x[dof + i] + dt * dt / 2 * u[i]);
+            xn[dof + i] = x[dof + i] + dt * u[i];
+        }
+    }
+    if (tm) xn[nx - 1] = x[nx - 1] + dt;
+    if (A) {
+        memset(A, 0, sizeof(double) * nx * nx);
+        for (int i = 0; i < nx; i++) A[i * nx + i] = 1;
+        if (nd == 2)
+            for (int i = 0; i < dof; i++) A[i * nx + dof + i] = dt;
+    }
+    if (B) {
+        memset(B, 0, sizeof(double) * nx * nu);
+        if (nd == 1) {
+            for (int i = 0; i < dof; i++) B[i * nu + i] = dt;
+            if (tm) {
+                for (int i = 0; i < dof; i++) B[i * nu + nu - 1] = 2 * dtSqrt * u[i];
+                B[(nx - 1) * nu + nu - 1] = 2 * dtSqrt;
+            }
+        } else {
+            for (int i = 0; i < dof; i++) {
+                B[i * nu + i] = dt * dt / 2;
+                B[(dof + i) * nu + i] = dt;
+            }
+            if (tm) { /* PosOrnTimePlannerSys.cpp:176: uses the velocity AFTER the step */
+                for (int i = 0; i < dof; i++) {
+                    B[i * nu + nu - 1] = 2 * dtSqrt * xn[dof + i] + 2 * dtSqrt * dtSqrt * dtSqrt * u[i];
+                    B[(dof + i) * nu + nu - 1] = 2 * dtSqrt * u[i];
+                }
+                B[(nx - 1) * nu + nu - 1] = 2 * dtSqrt;
+            }
+        }
+    }
+    if (fx_next || J) orc_get_fx_jac(s, xn, fx_next, J);
+    if (x_next) memcpy(x_next, xn, sizeof(double) * nx);
+}
+
+static void init_state(const orc_system* s, double* x0) {
+    int dof = s->dof;
+    memset(x0, 0, sizeof(double) * s->n_x);
+    memcpy(x0, s->q0, sizeof(double) * dof);
+    if (s->nb_deriv == 2) memcpy(x0 + dof, s->dq0, sizeof(double) * dof);
+}
+
+/* ------------------------------------------------------------------ ILQRRecursive::solve (solver/ILQRRecursive.cpp:21-181)
+ * and AL_ILQR::solve (solver/AL-ILQR.cpp:50-232) share this body; c == NULL -> plain recursive. */
+
+static int solve_riccati(const orc_system* s, const orc_constraints* c, double* lambda,
+                         const double* U0, int nb_iter, int lag_update_step, double penalty, double scaling,
+                         int line_search, int early_stop,
+                         double* Xo, double* fXo, double* Uo, double* Ko, double* dout, double* cost_out,
+                         double* trace_cost, double* trace_alpha) {
+    const int T = s->T, nx = s->n_x, nu = s->n_u, nf = s->n_f;
+    const int m = c ? c->m : 0, ns = nx + nu;
+    double* X = (double*)calloc((size_t)T * nx, 8);
+    double* fX = (double*)calloc((size_t)T * nf, 8);
+    double* U = (double*)calloc((size_t)(T - 1) * nu, 8);
+    double* nX = (double*)calloc((size_t)T * nx, 8);
+    double* nfX = (double*)calloc((size_t)T * nf, 8);
+    double* nU = (double*)calloc((size_t)(T - 1) * nu, 8);
+    double* As = (double*)calloc((size_t)(T - 1) * nx * nx, 8);
+    double* Bs = (double*)calloc((size_t)(T - 1) * nx * nu, 8);
+    double* Ks = (double*)calloc((size_t)(T - 1) * nu * nx, 8); /* indexed by timestep k */
+    double* ds = (double*)calloc((size_t)(T - 1) * nu, 8);
+    double* Is = m ? (double*)calloc((size_t)(T - 1) * m, 8) : NULL; /* penalty * diag(I_k) */
+    double* Cs = m ? (double*)calloc((size_t)(T - 1) * m, 8) : NULL; /* g_k */
+    double zero_u[ORC_MAX_NU] = {0};
+    double alpha = 1;
+    int it_done = 0;
+
+    init_state(s, X);
+    orc_get_fx_jac(s, X, fX, NULL);
+    memcpy(U, U0, sizeof(double) * (T - 1) * nu);
+
+#define CON_A(k) (c->A + (c->per_step ? (size_t)(k) * m * ns : 0))
+#define CON_B(k) (c->b + (c->per_step ? (size_t)(k) * m : 0))
+    /* AL_ILQR::constraints, AL-ILQR.cpp:21-44 (stored pre-multiplied by the current penalty, :72,190) */
+#define CONSTRAINTS(k, xk, uk)                                                                   \
+    do {                                                                                         \
+        double sk[ORC_MAX_NX + ORC_MAX_NU];                                                      \
+        memcpy(sk, (xk), sizeof(double) * nx);                                                   \
+        memcpy(sk + nx, (uk), sizeof(double) * nu);                                              \
+        for (int r_ = 0; r_ < m; r_++) {                                                         \
+            double g_ = dot(CON_A(k) + (size_t)r_ * ns, sk, ns) - CON_B(k)[r_];                  \
+            double i_ = 1;                                                                       \
+            if (g_ < 0 && lambda[(size_t)(k) * m + r_] == 0) i_ = 0;                              \
+            Is[(size_t)(k) * m + r_] = penalty * i_;                                             \
+            Cs[(size_t)(k) * m + r_] = g_;                                                       \
+        }                                                                                        \
+    } while (0)
+
+    /* initial rollout: ILQRRecursive.cpp:41-56 / AL-ILQR.cpp:68-85 */
+    double cost0 = 0;
+    for (int i = 0; i < T - 1; i++) {
+        const double* xk = X + (size_t)i * nx;
+        const double* uk = U + (size_t)i * nu;
+        if (m) CONSTRAINTS(i, xk, uk);
+        cost0 += orc_cost(s, xk, uk, i);
+        orc_step(s, xk, uk, X + (size_t)(i + 1) * nx, fX + (size_t)(i + 1) * nf,
+                 As + (size_t)i * nx * nx, Bs + (size_t)i * nx * nu, NULL);
+    }
+    cost0 += orc_cost(s, X + (size_t)(T - 1) * nx, zero_u, T - 1);
+
+    for (int it = 0; it < nb_iter; it++) {
+        /* ---------------- backward pass: ILQRRecursive.cpp:68-97 / AL-ILQR.cpp:94-145 */
+        double P[ORC_MAX_NX * ORC_MAX_NX], p[ORC_MAX_NX];
+        orc_cost_xx(s, X + (size_t)(T - 1) * nx, T - 1, P);
+        orc_cost_x(s, X + (size_t)(T - 1) * nx, T - 1, p);
+        for (int k = T - 2; k >= 0; k--) {
+            const double* xk = X + (size_t)k * nx;
+            const double* uk = U + (size_t)k * nu;
+            const double* A = As + (size_t)k * nx * nx;
+            const double* B = Bs + (size_t)k * nx * nu;
+            double BtP[ORC_MAX_NU * ORC_MAX_NX], AtP[ORC_MAX_NX * ORC_MAX_NX];
+            double Qux[ORC_MAX_NU * ORC_MAX_NX], Quu[ORC_MAX_NU * ORC_MAX_NU], Qxx[ORC_MAX_NX * ORC_MAX_NX];
+            double Qxu[ORC_MAX_NX * ORC_MAX_NU], Qu[ORC_MAX_NU], Qx[ORC_MAX_NX];
+            double lxx[ORC_MAX_NX * ORC_MAX_NX], lx[ORC_MAX_NX], tmp[ORC_MAX_NX * ORC_MAX_NX];
+            mtm(BtP, B, P, nx, nu, nx);
+            mtm(AtP, A, P, nx, nx, nx);
+            mm(Qux, BtP, A, nu, nx, nx);                 /* cost_ux = 0 */
+            mm(Quu, BtP, B, nu, nx, nu);
+            for (int i = 0; i < nu; i++) Quu[i * nu + i] = s->R_diag[i] + Quu[i * nu + i];
+            orc_cost_xx(s, xk, k, lxx);
+            mm(tmp, AtP, A, nx, nx, nx);
+            for (int i = 0; i < nx * nx; i++) Qxx[i] = lxx[i] + tmp[i];
+            mm(Qxu, AtP, B, nx, nx, nu);                 /* cost_xu = 0 */
+            mtm(Qu, B, p, nx, nu, 1);
+            for (int i = 0; i < nu; i++) Qu[i] = s->R_diag[i] * uk[i] + Qu[i]; /* cost_u = R u for ALL k */
+            orc_cost_x(s, xk, k, lx);
+            mtm(Qx, A, p, nx, nx, 1);
+            for (int i = 0; i < nx; i++) Qx[i] = lx[i] + Qx[i];
+            if (m) { /* AL-ILQR.cpp:110-134 */
+                const double* Ak = CON_A(k);
+                const double* Ik = Is + (size_t)k * m;
+                const double* ck = Cs + (size_t)k * m;
+                const double* lam = lambda + (size_t)k * m;
+                for (int r = 0; r < m; r++) {
+                    const double* ax = Ak + (size_t)r * ns;
+                    const double* au = ax + nx;
+                    double wv = lam[r] + Ik[r] * ck[r];
+                    for (int i = 0; i < nu; i++) {
+                        for (int j = 0; j < nx; j++) Qux[i * nx + j] += au[i] * Ik[r] * ax[j];
+                        for (int j = 0; j < nu; j++) Quu[i * nu + j] += au[i] * Ik[r] * au[j];
+                        Qu[i] += au[i] * wv;
+                    }
+                    for (int i = 0; i < nx; i++) {
+                        for (int j = 0; j < nx; j++) Qxx[i * nx + j] += ax[i] * Ik[r] * ax[j];
+                        for (int j = 0; j < nu; j++) Qxu[i * nu + j] += ax[i] * Ik[r] * au[j];
+                        Qx[i] += ax[i] * wv;
+                    }
+                }
+            }
+            /* Quu_inv = -(Quu + 1e-6 I)^-1 ; regularisation only inside the inverse (quirk D-3) */
+            double Qr[ORC_MAX_NU * ORC_MAX_NU], Qi[ORC_MAX_NU * ORC_MAX_NU];
+            memcpy(Qr, Quu, sizeof(double) * nu * nu);
+            for (int i = 0; i < nu; i++) Qr[i * nu + i] += 1e-6;
+            orc_inverse(nu, Qr, Qi);
+            for (int i = 0; i < nu * nu; i++) Qi[i] = -1 * Qi[i];
+            double* Kk = Ks + (size_t)k * nu * nx;
+            double* dk = ds + (size_t)k * nu;
+            mm(Kk, Qi, Qux, nu, nu, nx);
+            mm(dk, Qi, Qu, nu, nu, 1);
+            /* P = Qxx + K'QuuK + K'Qux + QxuK ; p = Qx + K'Quu d + K'Qu + Qxu d */
+            double KtQuu[ORC_MAX_NX * ORC_MAX_NU], t1[ORC_MAX_NX * ORC_MAX_NX], t2[ORC_MAX_NX * ORC_MAX_NX], t3[ORC_MAX_NX * ORC_MAX_NX];
+            double v1[ORC_MAX_NX], v2[ORC_MAX_NX], v3[ORC_MAX_NX];
+            mtm(KtQuu, Kk, Quu, nu, nx, nu);
+            mm(t1, KtQuu, Kk, nx, nu, nx);
+            mtm(t2, Kk, Qux, nu, nx, nx);
+            mm(t3, Qxu, Kk, nx, nu, nx);
+            for (int i = 0; i < nx * nx; i++) P[i] = ((Qxx[i] + t1[i]) + t2[i]) + t3[i];
+            mm(v1, KtQuu, dk, nx, nu, 1);
+            mtm(v2, Kk, Qu, nu, nx, 1);
+            mm(v3, Qxu, dk, nx, nu, 1);
+            for (int i = 0; i < nx; i++) p[i] = ((Qx[i] + v1[i]) + v2[i]) + v3[i];
+        }
+
+        /* ---------------- forward pass with step-halving line search: ILQRRecursive.cpp:101-155 */
+        alpha = 2;
+        double newCost = 0, dun = 0;
+        do {
+            alpha /= 2.0;
+            init_state(s, nX);
+            orc_get_fx_jac(s, nX, nfX, NULL);
+            dun = 0;
+            newCost = 0;
+            for (int k = 0; k < T - 1; k++) {
+                const double* Kk = Ks + (size_t)k * nu * nx;
+                const double* dk = ds + (size_t)k * nu;
+                double dxv[ORC_MAX_NX], du[ORC_MAX_NU];
+                double* nuk = nU + (size_t)k * nu;
+                const double* nxk = nX + (size_t)k * nx;
+                for (int i = 0; i < nx; i++) dxv[i] = nxk[i] - X[(size_t)k * nx + i];
+                for (int i = 0; i < nu; i++) du[i] = dot(Kk + i * nx, dxv, nx) + alpha * dk[i];
+                dun += norm(du, nu); /* quirk D-5: accumulates ||du||, not ||du||^2 */
+                for (int i = 0; i < nu; i++) nuk[i] = U[(size_t)k * nu + i] + du[i];
+                orc_step(s, nxk, nuk, nX + (size_t)(k + 1) * nx, nfX + (size_t)(k + 1) * nf,
+                         As + (size_t)k * nx * nx, Bs + (size_t)k * nx * nu, NULL); /* last trial's A,B survive (D-7) */
+                if (m) CONSTRAINTS(k, nxk, nuk);
+                newCost += orc_cost(s, nxk, nuk, k);
+            }
+            newCost += orc_cost(s, nX + (size_t)(T - 1) * nx, zero_u, T - 1);
+        } while (((newCost >= cost0) || isnan(newCost)) && alpha > 1e-3 && line_search);
+
+        /* multiplier update: AL-ILQR.cpp:202-208 (uses the UPDATED penalty) */
+        if (m && ((it + 1) % lag_update_step == 0)) {
+            penalty *= scaling;
+            for (size_t i = 0; i < (size_t)(T - 1) * m; i++) {
+                double v = lambda[i] + penalty * Cs[i];
+                lambda[i] = v > 0 ? v : 0; /* cwiseMax(0) */
+            }
+        }
+
+        /* accept unconditionally (quirk D-4) */
+        cost0 = newCost;
+        memcpy(X, nX, sizeof(double) * T * nx);
+        memcpy(fX, nfX, sizeof(double) * T * nf);
+        memcpy(U, nU, sizeof(double) * (T - 1) * nu);
+        if (trace_cost) trace_cost[it] = cost0;
+        if (trace_alpha) trace_alpha[it] = alpha;
+        it_done = it + 1;
+        if (c) {
+            if (early_stop && alpha * sqrt(dun) < 1e-3) break; /* AL-ILQR.cpp:225 */
+        } else {
+            if (early_stop && alpha * sqrt(dun) < 1e-3 && cost0 < 1e-3) break; /* ILQRRecursive.cpp:174 */
+        }
+    }
+#undef CONSTRAINTS
+#undef CON_A
+#undef CON_B
+
+    if (Xo) memcpy(Xo, X, sizeof(double) * T * nx);
+    if (fXo) memcpy(fXo, fX, sizeof(double) * T * nf);
+    if (Uo) memcpy(Uo, U, sizeof(double) * (T - 1) * nu);
+    if (Ko) memcpy(Ko, Ks, sizeof(double) * (T - 1) * nu * nx);
+    if (dout) /* returned ds are scaled by the accepted alpha (ILQRRecursive.cpp:128,144,162) */
+        for (size_t i = 0; i < (size_t)(T - 1) * nu; i++) dout[i] = (it_done > 0 ? alpha : 1.0) * ds[i];
+    if (cost_out) *cost_out = cost0;
+    free(X); free(fX); free(U); free(nX); free(nfX); free(nU); free(As); free(Bs); free(Ks); free(ds);
+    free(Is); free(Cs);
+    return it_done;
+}
+
+int orc_solve_recursive(const orc_system* s, const double* U0, int nb_iter, int line_search, int early_stop,
+                        double* X, double* fX, double* U, double* K, double* d, double* cost,
+                        double* trace_cost, double* trace_alpha) {
+    return solve_riccati(s, NULL, NULL, U0, nb_iter, 1, 0.0, 1.0, line_search, early_stop, X, fX, U, K, d, cost,
+                         trace_cost, trace_alpha);
+}
+
+int orc_solve_al(const orc_system* s, const orc_constraints* c, double* lambda, const double* U0, int nb_iter,
+                 int lag_update_step, double penalty, double scaling, int line_search, int early_stop,
+                 double* X, double* fX, double* U, double* cost, double* trace_cost, double* trace_alpha) {
+    return solve_riccati(s, c, lambda, U0, nb_iter, lag_update_step, penalty, scaling, line_search, early_stop,
+                         X, fX, U, NULL, NULL, cost, trace_cost, trace_alpha);
+}
+
+/* ------------------------------------------------------------------ BatchILQRCP (solver/BatchILQRCP.cpp) */
+
+typedef struct {
+    double *fX, *qL, *A, *B, *J, *L; /* per step: fX[T][nf], qL[T][nx], A[T][nx*nx], B[T][nx*nu], J[T][nq*nx], L[T][nx] (diag) */
+} fp_batch;
+
+/* System::fpBatch, System.cpp:181-211 with forwardPassWithLimits :144-161 (limits on the PRE-step state) */
+static void fp_batch_run(const orc_system* s, const double* u, fp_batch* f) {
+    const int T = s->T, nx = s->n_x, nu = s->n_u, nf = s->n_f, nq = s->n_Q;
+    double x[ORC_MAX_NX], xn[ORC_MAX_NX];
+    init_state(s, x);
+    memset(f->qL, 0, sizeof(double) * T * nx);
+    memset(f->L, 0, sizeof(double) * T * nx);
+    orc_get_fx_jac(s, x, f->fX, f->J);
+    memset(f->A, 0, sizeof(double) * nx * nx);
+    for (int i = 0; i < nx; i++) f->A[i * nx + i] = 1;
+    memset(f->B, 0, sizeof(double) * nx * nu);
+    for (int i = 0; i < T - 1; i++) {
+        orc_step(s, x, u + (size_t)i * nu, xn, f->fX + (size_t)(i + 1) * nf, f->A + (size_t)(i + 1) * nx * nx,
+                 f->B + (size_t)(i + 1) * nx * nu, f->J + (size_t)(i + 1) * nq * nx);
+        limits(s, x, f->L + (size_t)(i + 1) * nx, f->qL + (size_t)(i + 1) * nx);
+        memcpy(x, xn, sizeof(x));
+    }
+}
+
+static double cp_cost(const orc_system* s, const fp_batch* f, const double* u, double* e_out) {
+    /* e'Qe + u'Ru + ql'L ql over keypoint rows: BatchILQRCP.cpp:135,150 */
+    const int T = s->T, nx = s->n_x, nu = s->n_u, nf = s->n_f, nq = s->n_Q;
+    double c_e = 0, c_u = 0, c_l = 0;
+    for (int t = 0; t < s->n_kp; t++) {
+        const orc_keypoint* kp = &s->kp[t];
+        int ts = kp->timestep;
+        double e[ORC_MAX_NQ], Qe[ORC_MAX_NQ];
+        orc_kp_diff(s, find_kp(s, ts), f->fX + (size_t)ts * nf, e); /* System::diff looks the keypoint up in the map */
+        for (int i = 0; i < nq; i++) Qe[i] = dot(kp->Q + i * nq, e, nq);
+        c_e += dot(e, Qe, nq);
+        if (e_out) memcpy(e_out + (size_t)t * nq, e, sizeof(double) * nq);
+        for (int i = 0; i < nx; i++) c_l += f->qL[(size_t)ts * nx + i] * f->L[(size_t)ts * nx + i] * f->qL[(size_t)ts * nx + i];
+    }
+    for (int k = 0; k < T - 1; k++)
+        for (int i = 0; i < nu; i++) c_u += u[(size_t)k * nu + i] * s->R_diag[i] * u[(size_t)k * nu + i];
+    return c_e + c_u + c_l;
+}
+
+int orc_solve_batch_cp(const orc_system* s, const double* psi, int Kw, double* u, int nb_iter, int early_stop,
+                       double* trace_cost, double* trace_alpha) {
+    const int T = s->T, nx = s->n_x, nu = s->n_u, nf = s->n_f, nq = s->n_Q, nkp = s->n_kp;
+    const int NU = (T - 1) * nu;
+    fp_batch f, ft;
+    fp_batch* fs[2] = {&f, &ft};
+    for (int i = 0; i < 2; i++) {
+        fs[i]->fX = (double*)calloc((size_t)T * nf, 8);
+        fs[i]->qL = (double*)calloc((size_t)T * nx, 8);
+        fs[i]->A = (double*)calloc((size_t)T * nx * nx, 8);
+        fs[i]->B = (double*)calloc((size_t)T * nx * nu, 8);
+        fs[i]->J = (double*)calloc((size_t)T * nq * nx, 8);
+        fs[i]->L = (double*)calloc((size_t)T * nx, 8);
+    }
+    double* Su = (double*)calloc((size_t)nkp * nx * NU, 8);
+    double* M = (double*)calloc((size_t)nx * (NU + nu), 8);
+    double* Mn = (double*)calloc((size_t)nx * (NU + nu), 8);
+    double* SP = (double*)calloc((size_t)nkp * nx * Kw, 8);
+    double* H = (double*)calloc((size_t)Kw * Kw, 8);
+    double* Hi = (double*)calloc((size_t)Kw * Kw, 8);
+    double* g = (double*)calloc((size_t)Kw, 8);
+    double* dw = (double*)calloc((size_t)Kw, 8);
+    double* du = (double*)calloc((size_t)NU, 8);
+    double* ut = (double*)calloc((size_t)NU, 8);
+    double* e = (double*)calloc((size_t)nkp * nq, 8);
+    int it_done = 0;
+
+    for (int it = 0; it < nb_iter; it++) {
+        fp_batch_run(s, u, &f);
+        /* buildSuJL, BatchILQRCP.cpp:61-97: M seeded with B_0 = 0 and sampled BEFORE the step-i update (quirk D-1) */
+        memset(Su, 0, sizeof(double) * nkp * nx * NU);
+        int mc = nu; /* current number of columns of M */
+        memset(M, 0, sizeof(double) * nx * (NU + nu));
+        for (int i = 0; i < T; i++) {
+            for (int t = 0; t < nkp; t++)
+                if (s->kp[t].timestep == i && i > 0)
+                    for (int r = 0; r < nx; r++) memcpy(Su + ((size_t)t * nx + r) * NU, M + (size_t)r * (NU + nu), sizeof(double) * mc);
+            if (i > 0) {
+                const double* At = f.A + (size_t)i * nx * nx;
+                const double* Bt = f.B + (size_t)i * nx * nu;
+                for (int r = 0; r < nx; r++) {
+                    for (int cc = 0; cc < mc; cc++) {
+                        double a = 0;
+                        for (int l = 0; l < nx; l++) a += At[r * nx + l] * M[(size_t)l * (NU + nu) + cc];
+                        Mn[(size_t)r * (NU + nu) + cc] = a;
+                    }
+                    for (int cc = 0; cc < nu; cc++) Mn[(size_t)r * (NU + nu) + mc + cc] = Bt[r * nu + cc];
+                }
+                mc += nu;
+                double* t_ = M; M = Mn; Mn = t_;
+            }
+        }
+        double cost0 = cp_cost(s, &f, u, e);
+        /* H = Psi'Su'(J'QJ + L)Su Psi + Psi'R Psi ; g = Psi'Su'(J'Q e + L ql) - Psi'R u   (:129-130) */
+        mm(SP, Su, psi, nkp * nx, NU, Kw);
+        memset(H, 0, sizeof(double) * Kw * Kw);
+        memset(g, 0, sizeof(double) * Kw);
+        for (int t = 0; t < nkp; t++) {
+            const orc_keypoint* kp = &s->kp[t];
+            int ts = kp->timestep;
+            const double* Jt = f.J + (size_t)ts * nq * nx;
+            double JtQ[ORC_MAX_NX * ORC_MAX_NQ], W[ORC_MAX_NX * ORC_MAX_NX], r[ORC_MAX_NX];
+            mtm(JtQ, Jt, kp->Q, nq, nx, nq);
+            mm(W, JtQ, Jt, nx, nq, nx);
+            mm(r, JtQ, e + (size_t)t * nq, nx, nq, 1);
+            for (int i = 0; i < nx; i++) {
+                W[i * nx + i] += f.L[(size_t)ts * nx + i];
+                r[i] += f.L[(size_t)ts * nx + i] * f.qL[(size_t)ts * nx + i];
+            }
+            const double* SPt = SP + (size_t)t * nx * Kw;
+            double* WS = (double*)malloc(sizeof(double) * nx * Kw);
+            mm(WS, W, SPt, nx, nx, Kw);
+            for (int a = 0; a < Kw; a++) {
+                for (int b = 0; b < Kw; b++) {
+                    double acc = 0;
+                    for (int l = 0; l < nx; l++) acc += SPt[l * Kw + a] * WS[l * Kw + b];
+                    H[a * Kw + b] += acc;
+                }
+                double acc = 0;
+                for (int l = 0; l < nx; l++) acc += SPt[l * Kw + a] * r[l];
+                g[a] += acc;
+            }
+            free(WS);
+        }
+        for (int a = 0; a < Kw; a++) {
+            for (int b = 0; b < Kw; b++) {
+                double acc = 0;
+                for (int k = 0; k < NU; k++) acc += psi[(size_t)k * Kw + a] * s->R_diag[k % nu] * psi[(size_t)k * Kw + b];
+                H[a * Kw + b] += acc;
+            }
+            double acc = 0;
+            for (int k = 0; k < NU; k++) acc += psi[(size_t)k * Kw + a] * s->R_diag[k % nu] * u[k];
+            g[a] -= acc;
+        }
+        orc_inverse(Kw, H, Hi); /* explicit .inverse(), :131 */
+        mm(dw, Hi, g, Kw, Kw, 1);
+        mm(du, psi, dw, NU, Kw, 1);
+
+        double alpha = 1.0;
+        while (1) { /* :138-158 */
+            for (int k = 0; k < NU; k++) ut[k] = u[k] + alpha * du[k];
+            fp_batch_run(s, ut, &ft);
+            double cost = cp_cost(s, &ft, ut, NULL);
+            if ((cost < cost0) || (alpha < 1e-3)) {
+                memcpy(u, ut, sizeof(double) * NU);
+                break;
+            }
+            alpha /= 2;
+        }
+        if (trace_cost) trace_cost[it] = cost0; /* printed cost is the PRE-step cost (:160) */
+        if (trace_alpha) trace_alpha[it] = alpha;
+        it_done = it + 1;
+        if (early_stop && alpha * norm(du, NU) < 1e-3) break; /* :167 */
+    }
+    for (int i = 0; i < 2; i++) { free(fs[i]->fX); free(fs[i]->qL); free(fs[i]->A); free(fs[i]->B); free(fs[i]->J); free(fs[i]->L); }
+    free(Su); free(M); free(Mn); free(SP); free(H); free(Hi); free(g); free(dw); free(du); free(ut); free(e);
+    return it_done;
+}
+
+/* ------------------------------------------------------------------ primitives (utils/primitives.cpp) */
+
+static int binom(int n, int k) { /* :13-17 */
+    if (k == 0 || k == n) return 1;
+    return binom(n - 1, k - 1) + binom(n - 1, k);
+}
+
+void orc_psi_rbf(int dim, int K, double* out) { /* :19-33 */
+    double bw = ((double)dim) / K, avg = bw / 2, sig = bw;
+    for (int i = 0; i < K; i++) {
+        for (int j = 0; j < dim; j++) {
+            double t = (double)j;
+            out[j * K + i] = 1 / (2 * M_PI * sig) * exp(-1 * (t - avg) * (t - avg) / (2 * sig * sig));
+        }
+        avg += bw;
+    }
+}
+
+void orc_psi_bernstein(int dim, int K, double* out) { /* :35-50 */
+    int order = K - 1;
+    for (int i = 0; i < K; i++) {
+        int b = binom(order, i);
+        for (int j = 0; j < dim; j++) {
+            double t = ((double)j) / (double)(dim - 1);
+            out[j * K + i] = b * pow(t, i) * pow(1 - t, order - i);
+        }
+    }
+}
+
+void orc_psi_unitstep(int dim, int K, double* out) { /* :52-68 */
+    int bw = (int)round(((double)dim) / K);
+    int lo = 0, hi = bw;
+    for (int i = 0; i < K; i++) {
+        for (int j = 0; j < dim; j++) out[j * K + i] = (j >= lo && j < hi) ? 1.0 / bw : 0;
+        lo += bw;
+        hi += bw;
+    }
+}
+
+void orc_psi_sawtooth(int dim, int K, double* out) { /* :70-86 */
+    int bw = (int)ceil(((double)dim) / K);
+    double lo = 0, hi = bw;
+    for (int i = 0; i < K; i++) {
+        for (int j = 0; j < dim; j++) out[j * K + i] = (j >= lo && j < hi) ? ((j - lo) / (bw - 1) - 0.5) : 0;
+        lo += bw;
+        hi += bw;
+    }
+}
+
+void orc_psi_linear(int dim, int K, double* out) { /* :88-94 */
+    double* a = (double*)malloc(sizeof(double) * dim * K);
+    double* b = (double*)malloc(sizeof(double) * dim * K);
+    orc_psi_unitstep(dim, K, a);
+    orc_psi_sawtooth(dim, K, b);
+    for (int j = 0; j < dim; j++)
+        for (int i = 0; i < K; i++) {
+            out[j * 2 * K + i] = a[j * K + i];
+            out[j * 2 * K + K + i] = b[j * K + i];
+        }
+    free(a);
+    free(b);
+}

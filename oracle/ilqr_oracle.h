@@ -1,0 +1,133 @@
+/*
+ * ilqr_oracle.h -- CPU restatement ("oracle") of the idiap/ilqr_planner hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under ilqr_planner_amd/ (the product) may include,
+ * link or call this.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * use it, and only as the checker / the timed CPU baseline.
+ *
+ * Plain C, IEEE double, single instance, single thread -- exactly the shape of the reference
+ * (one problem per solve() call).  Every function cites the reference file:line it restates;
+ * paths are relative to /root/reference/ilqr_planner/ilqr_planner ($L in SURVEY.md).
+ *
+ * Parity pin: the reference has no tests and cannot be built here (Eigen3 / orocos_kdl /
+ * tinyxml2 absent).  This restatement is pinned against the per-iteration cost
+ * traces stored in the reference's tutorial notebooks (tests/golden/traces.json), 6 significant
+ * digits of cost per iteration and the exact alpha sequence; orocos_kdl internals (un-vendored,
+ * unpinned version) are restated from their published algorithm and are pinned only through
+ * those traces plus the FK literals in the notebooks.
+ */
+#ifndef ILQR_ORACLE_H
+#define ILQR_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAX_SEG 24
+#define ORC_MAX_DOF 7
+#define ORC_MAX_NX 16
+#define ORC_MAX_NU 8
+#define ORC_MAX_NF 16
+#define ORC_MAX_NQ 14
+#define ORC_MAX_KP 8
+#define ORC_MAX_M 32
+
+enum { ORC_SYS_POS_ORN = 0, ORC_SYS_POS_ORN_TIME = 1 };
+
+/* URDF chain base->tip, as orocos_kdl sees it after TinyURDFParser: one segment per URDF joint,
+ * T_seg(q) = Trans(xyz) * R_fixed * Rot(axis, q)  (fixed joints: no Rot), then the user tool frame
+ * Frame(EulerZYX(rpy0,rpy1,rpy2), xyz) appended as a fixed segment (src/sim/KDLRobot.cpp:61-66). */
+typedef struct {
+    int n_seg;
+    int dof;
+    int seg_joint[ORC_MAX_SEG];     /* -1 = fixed segment, else moving-joint index 0..dof-1 */
+    double seg_xyz[ORC_MAX_SEG][3];
+    double seg_R[ORC_MAX_SEG][9];   /* row-major fixed rotation of the joint origin */
+    double seg_axis[ORC_MAX_SEG][3];
+} orc_chain;
+
+typedef struct {
+    int timestep;
+    double pos[3], orn[4];      /* orn = (w,x,y,z) */
+    double dpos[3], dorn[4];    /* 2nd order only */
+    double ctime;               /* time systems only */
+    double Q[ORC_MAX_NQ * ORC_MAX_NQ]; /* row-major n_Q x n_Q precision */
+} orc_keypoint;
+
+typedef struct {
+    orc_chain chain;
+    int kind;       /* ORC_SYS_* */
+    int nb_deriv;   /* 1 or 2 */
+    int T;          /* horizon */
+    double dt;      /* PosOrn only */
+    double R_diag[ORC_MAX_NU];
+    int limits_set;
+    double penalty;                       /* System.cpp:40,72 */
+    double state_max[ORC_MAX_NX], state_min[ORC_MAX_NX];
+    int limit_weight[ORC_MAX_NX];
+    double q0[ORC_MAX_DOF], dq0[ORC_MAX_DOF];
+    int n_kp;
+    orc_keypoint kp[ORC_MAX_KP];
+    /* derived by orc_system_finalize() (localInit, PosOrnPlannerSys.cpp:54-78 / PosOrnTimePlannerSys.cpp:50-83) */
+    int dof, n_x, n_u, n_f, n_Q;
+} orc_system;
+
+void orc_system_finalize(orc_system* s);
+
+/* KDLRobot::updateKinematics (src/sim/KDLRobot.cpp:83-115) */
+void orc_fk(const orc_chain* c, const double* q, const double* dq,
+            double p[3], double quat[4], double J[6 * ORC_MAX_DOF], double dx[3], double w[3]);
+
+/* include/ilqr_planner/utils/sd.h */
+void orc_sd_H(const double q[4], double H[12]);                              /* :23-27 */
+double orc_sd_distance(const double x[4], const double y[4]);                /* :48-62 */
+void orc_sd_logmap(const double base[4], const double y[4], double out[4]);  /* :67-82 */
+void orc_sd_expmap(const double base[4], const double u[4], double out[4]);  /* :32-43 */
+void orc_sd_transport(const double v[4], const double b1[4], const double b2[4], double out[4]); /* :87-99 */
+
+/* System virtuals */
+void orc_get_fx_jac(const orc_system* s, const double* x, double* fx, double* J /* n_Q x n_x, may be NULL */);
+void orc_kp_diff(const orc_system* s, const orc_keypoint* kp, const double* fx, double* e);
+double orc_cost(const orc_system* s, const double* x, const double* u, int k);
+void orc_cost_x(const orc_system* s, const double* x, int k, double* lx);
+void orc_cost_xx(const orc_system* s, const double* x, int k, double* lxx);
+/* forwardPass: x_next, fx_next, A (n_x^2), B (n_x*n_u), J (n_Q*n_x); any output may be NULL */
+void orc_step(const orc_system* s, const double* x, const double* u,
+              double* x_next, double* fx_next, double* A, double* B, double* J);
+
+/* Solvers.  All trajectories row-major [t][dim].  trace_* have nb_iter entries; returns iterations run. */
+int orc_solve_recursive(const orc_system* s, const double* U0, int nb_iter, int line_search, int early_stop,
+                        double* X, double* fX, double* U, double* K, double* d, double* cost,
+                        double* trace_cost, double* trace_alpha);
+
+typedef struct {
+    int m;              /* rows of each A_k */
+    int per_step;       /* 0: one (A,b) for all k; 1: A,b are [T-1][...] */
+    const double* A;    /* m x (n_x+n_u) row-major */
+    const double* b;    /* m */
+} orc_constraints;
+
+int orc_solve_al(const orc_system* s, const orc_constraints* c, double* lambda /* [T-1][m], in/out */,
+                 const double* U0, int nb_iter, int lag_update_step, double penalty, double scaling,
+                 int line_search, int early_stop,
+                 double* X, double* fX, double* U, double* cost, double* trace_cost, double* trace_alpha);
+
+/* BatchILQRCP::solve; Qbig = block-diag keypoint precisions built from the system (getQMatrix(true)).
+ * psi: ((T-1) n_u) x Kw row-major.  u: in = u0, out = solution ((T-1) n_u). */
+int orc_solve_batch_cp(const orc_system* s, const double* psi, int Kw, double* u, int nb_iter, int early_stop,
+                       double* trace_cost, double* trace_alpha);
+
+/* primitives.cpp:19-96; out is dim x K (x 2K for linear) row-major */
+void orc_psi_rbf(int dim, int K, double* out);
+void orc_psi_bernstein(int dim, int K, double* out);
+void orc_psi_unitstep(int dim, int K, double* out);
+void orc_psi_sawtooth(int dim, int K, double* out);
+void orc_psi_linear(int dim, int K, double* out);
+
+/* general inverse by LU with partial pivoting (Eigen MatrixXd::inverse() = PartialPivLU). returns 0 ok */
+int orc_inverse(int n, const double* A, double* Ainv);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,73 @@
+"""Shared test helpers: load golden fixtures, build oracle Systems, synthetic batches."""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import oracle as orc  # noqa: E402  (tests are allowed to use the oracle)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def urdf_text():
+    return open(os.path.join(GOLDEN, "panda_chain.urdf")).read()
+
+
+def golden():
+    return json.load(open(os.path.join(GOLDEN, "traces.json")))
+
+
+def panda_segs(tool_rpy=(0, 0, 0), tool_xyz=(0, 0, 0)):
+    return orc.chain_from_urdf(urdf_text(), "panda_link0", "panda_tip", tool_rpy, tool_xyz)
+
+
+def oracle_system(prob, segs=None):
+    segs = segs or panda_segs()
+    kind = orc.SYS_POS_ORN if prob["kind"] == "POS_ORN" else orc.SYS_POS_ORN_TIME
+    kps = []
+    for k in prob["keypoints"]:
+        d = dict(k)
+        d["Q"] = np.diag(k["Qdiag"]) if "Qdiag" in k else np.asarray(k["Q"])
+        kps.append(d)
+    return orc.make_system(segs, kind, prob["nb_deriv"], prob["T"], prob["dt"], prob["R_diag"], kps, prob["q0"], prob["dq0"],
+                           prob.get("qMax"), prob.get("qMin"), prob.get("dqMax"), prob.get("dqMin"))
+
+
+def u0_of(prob):
+    return np.tile(np.asarray(prob["u0_step"], float), prob["T"] - 1)
+
+
+def psi_of(spec, T, n_u):
+    """PSI matrices exactly as the tutorial cells build them."""
+    K = spec["K"]
+    if spec["kind"] in ("unitstep", "sawtooth", "rbf", "bernstein"):
+        return np.kron(orc.psi(spec["kind"], T - 1, K), np.eye(n_u))
+    if spec["kind"] == "sawtooth+unitstep_dt":
+        a = np.diag([1.0] * (n_u - 1) + [0.0])
+        b = np.diag([0.0] * (n_u - 1) + [1.0])
+        return np.kron(orc.psi("sawtooth", T - 1, K), a) + np.kron(orc.psi("unitstep", T - 1, K), b)
+    raise KeyError(spec["kind"])
+
+
+def sig6(x):
+    """Value as the reference prints it (default ostream precision 6)."""
+    return float("%.6g" % x)
+
+
+def assert_trace(got_cost, got_alpha, trace):
+    assert len(got_cost) == len(trace), (len(got_cost), len(trace))
+    for i, ((c_ref, a_ref), c, a) in enumerate(zip(trace, got_cost, got_alpha)):
+        assert sig6(a) == a_ref, f"iteration {i+1}: alpha {a} != {a_ref}"
+        if c_ref is None:
+            assert np.isnan(c), f"iteration {i+1}: expected nan, got {c}"
+        else:
+            # the printed value has 6 significant digits: allow half a unit in the last place (+ slack for rounding ties)
+            ulp6 = 10.0 ** (np.floor(np.log10(abs(c_ref))) - 5)
+            assert abs(c - c_ref) <= 0.51 * ulp6, f"iteration {i+1}: cost {c!r} vs {c_ref!r}"

@@ -1,0 +1,90 @@
+"""Pins the CPU oracle (oracle/ilqr_oracle.c) against every known-answer value the reference holds for the
+hot path: the per-iteration cost/alpha streams stored in its tutorial notebooks (6 significant digits,
+exact alpha sequence, exact iteration count incl. early stop and the -nan divergence) and the FK literal.
+The reference has no tests of its own."""
+import numpy as np
+import pytest
+
+from tests.helpers import assert_trace, golden, oracle_system, orc, panda_segs, psi_of, u0_of
+
+G = golden()
+CASES = [(n, i) for n, c in G["cases"].items() for i, s in enumerate(c["solves"]) if s["solver"] != "BatchILQR"]
+
+
+def test_fk_literal_from_notebook():
+    # POS_ORN_MULTI_SYS.ipynb cell 8 stores FK(q0)'s quaternion incl. the negative w (pins KDL GetQuaternion's branch)
+    ch = orc.make_chain(panda_segs())
+    p, quat, J, _, _ = orc.fk(ch, G["fk_kat"]["q0"])
+    np.testing.assert_allclose(quat, G["fk_kat"]["quat_from_notebook"], atol=5e-9)
+    np.testing.assert_allclose(p, [0.38162676, 0.28572033, 0.57378428], atol=5e-9)
+    p0, quat0, _, _, _ = orc.fk(ch, np.zeros(7))
+    np.testing.assert_allclose(p0, [0.088, 0, 0.8226], atol=1e-9)
+    np.testing.assert_allclose(quat0, [0, 0.92387953, 0.38268343, 0], atol=1e-8)
+
+
+def test_jacobian_matches_finite_difference():
+    ch = orc.make_chain(panda_segs((0.1, -0.2, 0.3), (0.01, 0.02, 0.03)))
+    rng = np.random.default_rng(0)
+    for _ in range(5):
+        q = rng.uniform(-2, 2, 7)
+        p, quat, J, _, _ = orc.fk(ch, q)
+        h = 1e-6
+        for j in range(7):
+            qp, qm = q.copy(), q.copy()
+            qp[j] += h
+            qm[j] -= h
+            pp, quatp, *_ = orc.fk(ch, qp)
+            pm, quatm, *_ = orc.fk(ch, qm)
+            np.testing.assert_allclose((pp - pm) / (2 * h), J[:3, j], atol=1e-7)
+            # angular part: w = 2 H(q) dq/dt
+            if np.dot(quatp, quatm) < 0:
+                quatm = -quatm
+            dq = (quatp - quatm) / (2 * h)
+            H = np.array([[-quat[1], quat[0], -quat[3], quat[2]], [-quat[2], quat[3], quat[0], -quat[1]], [-quat[3], -quat[2], quat[1], quat[0]]])
+            np.testing.assert_allclose(2 * H @ dq, J[3:, j], atol=1e-6)
+
+
+@pytest.mark.parametrize("name,idx", CASES, ids=[f"{n}-{G['cases'][n]['solves'][i]['solver']}" for n, i in CASES])
+def test_trace(name, idx):
+    case = G["cases"][name]
+    sv = case["solves"][idx]
+    s = oracle_system(case["problem"])
+    u0 = u0_of(case["problem"])
+    if sv["solver"] == "ILQRRecursive":
+        r = orc.solve_recursive(s, u0, sv["nb_iter"], sv["line_search"], sv["early_stop"])
+    elif sv["solver"] == "BatchILQRCP":
+        r = orc.solve_batch_cp(s, psi_of(sv["psi"], s.T, s.n_u), u0, sv["nb_iter"], sv["early_stop"])
+    else:
+        m = sv["m"]
+        A, b = np.zeros((m, s.n_x + s.n_u)), np.zeros(m)
+        for i, j, v in sv["A_nonzero"]:
+            A[i, j] = v
+        for i, v in sv["b_nonzero"]:
+            b[i] = v
+        r = orc.solve_al(s, A, b, np.tile(b, (s.T - 1, 1)), u0, sv["nb_iter"], sv["lag_update_step"], sv["penalty"],
+                         sv["scaling_factor"], sv["line_search"], sv["early_stop"])
+    assert_trace(r["trace_cost"], r["trace_alpha"], sv["trace"])
+
+
+def test_initial_costs():
+    # initial costs printed by the CP solver = cost of the zero-control rollout (SURVEY.md 8c KATs)
+    for name, c0 in (("POS_ORN_SYS", 0.506613), ("POS_ORN_TIME_SYS", 3.41273), ("POS_ORN_TIME_SYS_2ND", 4.04153)):
+        case = G["cases"][name]
+        s = oracle_system(case["problem"])
+        sv = [x for x in case["solves"] if x["solver"] == "BatchILQRCP"][0]
+        r = orc.solve_batch_cp(s, psi_of(sv["psi"], s.T, s.n_u), u0_of(case["problem"]), 1, False)
+        assert float("%.6g" % r["trace_cost"][0]) == c0
+
+
+def test_inverse_and_primitives():
+    rng = np.random.default_rng(1)
+    A = rng.normal(size=(8, 8))
+    np.testing.assert_allclose(orc.inverse(A) @ A, np.eye(8), atol=1e-10)
+    ps = orc.psi("unitstep", 99, 2)
+    assert ps.shape == (99, 2) and abs(ps[:50, 0].sum() - 1.0) < 1e-12 and ps[50:, 0].sum() == 0  # bw = round(49.5) = 50
+    saw = orc.psi("sawtooth", 399, 2)
+    assert saw[0, 0] == -0.5 and abs(saw[199, 0] - 0.5) < 1e-12 and saw[200, 0] == 0 and saw[200, 1] == -0.5
+    lin = orc.psi("linear", 10, 2)
+    assert lin.shape == (10, 4)
+    bern = orc.psi("bernstein", 11, 4)
+    np.testing.assert_allclose(bern.sum(1), 1.0, atol=1e-12)
