@@ -1,0 +1,584 @@
+// ilqr_capi.cpp -- implementation of the C ABI declared in include/ilqr_hip.h (compiled with hipcc).
+//
+// Host-side orchestration only: lowering of the POD problem description to the device descriptor, buffer
+// ownership, layout conversion at the boundary and the per-iteration launch sequence
+//   init rollout -> nb_iter x { backward sweep, forward line search }
+// which mirrors ILQRRecursive::solve / AL_ILQR::solve (reference src/solver/ILQRRecursive.cpp:21-181,
+// src/solver/AL-ILQR.cpp:50-232).  No CPU fallback exists: every entry point fails loudly if HIP does.
+#include "../../include/ilqr_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ilqr_batchcp.hpp"
+#include "ilqr_kernels.hpp"
+
+using namespace ilqr;
+
+struct ilqr_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool profile = false;
+    double prof_ms[ILQR_PROF_COUNT] = {0, 0, 0, 0};
+    int prof_n[ILQR_PROF_COUNT] = {0, 0, 0, 0};
+    struct Pending { hipEvent_t a, b; int which; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> pool;
+};
+
+struct ilqr_problem {
+    ilqr_ctx* ctx = nullptr;
+    ilqr_problem_desc desc;
+    ilqr_dims dims;
+    int B = 0, Bp = 0, T = 0;
+    DevDesc hdesc;
+    DevDesc* ddesc = nullptr;
+    Bufs bufs;
+    std::vector<void*> allocs;
+    double *conA = nullptr, *conb = nullptr;  // device copies of the shared constraint rows
+    double* lambda0 = nullptr;                // initial multipliers, kept for ilqr_problem_reset_multipliers
+    int trace_iters = 0;
+    double* staging = nullptr;  // device staging for host<->device natural-layout transfers
+    size_t staging_elems = 0;
+    int last_nb_iter = 0;
+    bool has_controls = false, has_state = false;
+    BatchCPState cp;
+};
+
+static int fail(ilqr_ctx* c, const std::string& m) {
+    if (c) c->err = m;
+    return 1;
+}
+#define HIPCHK(ctx, call)                                                                                  \
+    do {                                                                                                   \
+        hipError_t e_ = (call);                                                                            \
+        if (e_ != hipSuccess) return fail((ctx), std::string(#call) + ": " + hipGetErrorString(e_));       \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------ misc
+
+extern "C" const char* ilqr_version(void) { return "ilqr_hip 0.1 (gfx950, fp64)"; }
+
+extern "C" void ilqr_desc_defaults(ilqr_problem_desc* d) {
+    std::memset(d, 0, sizeof(*d));
+    d->reg = 1e-6;
+    d->alpha_floor = 1e-3;
+    d->stop_tol = 1e-3;
+    d->nb_deriv = 1;
+    d->dof = 7;
+}
+
+extern "C" int ilqr_dims_of(const ilqr_problem_desc* d, ilqr_dims* o) {
+    if (!d || !o) return 1;
+    if (d->kind != ILQR_SYS_POS_ORN && d->kind != ILQR_SYS_POS_ORN_TIME) return 1;
+    if (d->nb_deriv != 1 && d->nb_deriv != 2) return 1;
+    const int tm = d->kind == ILQR_SYS_POS_ORN_TIME ? 1 : 0;
+    o->n_x = d->nb_deriv * d->dof + tm;  // PosOrnPlannerSys.cpp:74 / PosOrnTimePlannerSys.cpp:67
+    o->n_u = d->dof + tm;
+    o->n_f = 7 * d->nb_deriv + tm;
+    o->n_Q = o->n_f - d->nb_deriv;
+    return 0;
+}
+
+extern "C" int ilqr_ctx_create(int device_id, ilqr_ctx** out) {
+    if (!out) return 1;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 2;  // no HIP device: fail loudly, there is no CPU path
+    if (device_id < 0 || device_id >= n) return 3;
+    if (hipSetDevice(device_id) != hipSuccess) return 4;
+    auto* c = new ilqr_ctx();
+    c->device = device_id;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return 5;
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return 0;
+}
+
+extern "C" void ilqr_ctx_destroy(ilqr_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto e : c->pool) (void)hipEventDestroy(e);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+extern "C" const char* ilqr_last_error(const ilqr_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+extern "C" int ilqr_ctx_set_stream(ilqr_ctx* c, void* s) {
+    if (!c) return 1;
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return 0;
+}
+
+extern "C" int ilqr_ctx_synchronize(ilqr_ctx* c) {
+    if (!c) return 1;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ profiling
+
+static hipEvent_t ev_get(ilqr_ctx* c) {
+    if (!c->pool.empty()) {
+        hipEvent_t e = c->pool.back();
+        c->pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+static void prof_collect(ilqr_ctx* c) {
+    if (c->pending.empty()) return;
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& p : c->pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            c->prof_ms[p.which] += ms;
+            c->prof_n[p.which] += 1;
+        }
+        c->pool.push_back(p.a);
+        c->pool.push_back(p.b);
+    }
+    c->pending.clear();
+}
+struct ProfScope {  // brackets ONE kernel launch with events on the launch stream
+    ilqr_ctx* c;
+    hipEvent_t a = nullptr, b = nullptr;
+    int which;
+    ProfScope(ilqr_ctx* c_, int w) : c(c_), which(w) {
+        if (c->profile) {
+            a = ev_get(c);
+            b = ev_get(c);
+            (void)hipEventRecord(a, c->stream);
+        }
+    }
+    ~ProfScope() {
+        if (c->profile) {
+            (void)hipEventRecord(b, c->stream);
+            c->pending.push_back({a, b, which});
+        }
+    }
+};
+
+extern "C" int ilqr_profile_enable(ilqr_ctx* c, int on) {
+    if (!c) return 1;
+    prof_collect(c);
+    c->profile = on != 0;
+    return 0;
+}
+extern "C" int ilqr_profile_reset(ilqr_ctx* c) {
+    if (!c) return 1;
+    prof_collect(c);
+    for (int i = 0; i < ILQR_PROF_COUNT; i++) { c->prof_ms[i] = 0; c->prof_n[i] = 0; }
+    return 0;
+}
+extern "C" int ilqr_profile_get(ilqr_ctx* c, int which, double* ms, int* n) {
+    if (!c || which < 0 || which >= ILQR_PROF_COUNT) return 1;
+    prof_collect(c);
+    if (ms) *ms = c->prof_ms[which];
+    if (n) *n = c->prof_n[which];
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ lowering
+
+static void mat3(const double* A, const double* B, double* C) {
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+
+// Fold runs of fixed segments into the following joint's pre-transform; the rest becomes the tail.
+static int lower_chain(ilqr_ctx* c, const ilqr_problem_desc& d, DevChain& ch) {
+    if (d.dof != DOF) return fail(c, "device path supports chains with exactly 7 moving joints (got " + std::to_string(d.dof) + ")");
+    if (d.n_seg < 1 || d.n_seg > ILQR_MAX_SEG) return fail(c, "bad n_seg");
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {0, 0, 0};
+    int nj = 0;
+    for (int s = 0; s < d.n_seg; s++) {
+        double Rn[9];
+        for (int i = 0; i < 3; i++) p[i] += R[3 * i] * d.seg_xyz[s][0] + R[3 * i + 1] * d.seg_xyz[s][1] + R[3 * i + 2] * d.seg_xyz[s][2];
+        mat3(R, d.seg_R[s], Rn);
+        std::memcpy(R, Rn, sizeof(R));
+        const int j = d.seg_joint[s];
+        if (j >= 0) {
+            if (j != nj || nj >= DOF) return fail(c, "moving joints must be numbered 0..dof-1 in chain order");
+            std::memcpy(ch.Rpre[nj], R, sizeof(R));
+            std::memcpy(ch.ppre[nj], p, sizeof(p));
+            std::memcpy(ch.axis[nj], d.seg_axis[s], 3 * sizeof(double));
+            nj++;
+            const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+            std::memcpy(R, I, sizeof(R));
+            p[0] = p[1] = p[2] = 0;
+        }
+    }
+    if (nj != DOF) return fail(c, "chain has " + std::to_string(nj) + " moving joints, descriptor says " + std::to_string(d.dof));
+    std::memcpy(ch.Rtail, R, sizeof(R));
+    std::memcpy(ch.ptail, p, sizeof(p));
+    return 0;
+}
+
+static int lower_desc(ilqr_ctx* c, const ilqr_problem_desc& d, int B, int Bp, DevDesc& h) {
+    ilqr_dims dm;
+    if (ilqr_dims_of(&d, &dm)) return fail(c, "unsupported system kind / nb_deriv");
+    std::memset(&h, 0, sizeof(h));
+    if (lower_chain(c, d, h.chain)) return 1;
+    if (d.horizon < 2) return fail(c, "horizon must be >= 2");
+    h.kind = d.kind; h.nd = d.nb_deriv; h.T = d.horizon; h.B = B; h.Bp = Bp; h.dt = d.dt;
+    for (int i = 0; i < dm.n_u; i++) h.R_diag[i] = d.R_diag[i];
+    h.limits_set = d.limits_set; h.penalty = d.penalty;
+    for (int i = 0; i < dm.n_x; i++) { h.smax[i] = d.state_max[i]; h.smin[i] = d.state_min[i]; h.lw[i] = d.limit_weight[i]; }
+    if (d.n_kp < 0 || d.n_kp > ILQR_MAX_KP) return fail(c, "bad n_kp");
+    h.n_kp = d.n_kp;
+    for (int k = 0; k < d.n_kp; k++) {
+        if (d.kp_timestep[k] < 0 || d.kp_timestep[k] >= d.horizon) return fail(c, "keypoint timestep outside the horizon");
+        if (k > 0 && d.kp_timestep[k] <= d.kp_timestep[k - 1]) return fail(c, "keypoint timesteps must be unique and ascending");
+        h.kp_t[k] = d.kp_timestep[k];
+        for (int i = 0; i < dm.n_Q * dm.n_Q; i++) h.kp_Q[k][i] = d.kp_Q[k][i];
+    }
+    h.reg = d.reg; h.alpha_floor = d.alpha_floor; h.stop_tol = d.stop_tol;
+    return 0;
+}
+
+template <class T>
+static int dalloc(ilqr_problem* p, T** ptr, size_t n, bool zero = true) {
+    void* q = nullptr;
+    if (n == 0) n = 1;
+    HIPCHK(p->ctx, hipMalloc(&q, n * sizeof(T)));
+    p->allocs.push_back(q);
+    if (zero) HIPCHK(p->ctx, hipMemsetAsync(q, 0, n * sizeof(T), p->ctx->stream));
+    *ptr = (T*)q;
+    return 0;
+}
+
+static int ensure_staging(ilqr_problem* p, size_t elems) {
+    if (p->staging_elems >= elems) return 0;
+    if (p->staging) { HIPCHK(p->ctx, hipStreamSynchronize(p->ctx->stream)); HIPCHK(p->ctx, hipFree(p->staging)); p->staging = nullptr; }
+    HIPCHK(p->ctx, hipMalloc((void**)&p->staging, elems * sizeof(double)));
+    p->staging_elems = elems;
+    return 0;
+}
+
+extern "C" int ilqr_problem_create(ilqr_ctx* c, const ilqr_problem_desc* d, int batch, ilqr_problem** out) {
+    if (!c) return 1;
+    if (!d || !out || batch <= 0) return fail(c, "bad arguments");
+    *out = nullptr;
+    HIPCHK(c, hipSetDevice(c->device));
+    auto* p = new ilqr_problem();
+    p->ctx = c;
+    p->desc = *d;
+    p->B = batch;
+    p->Bp = (batch + 63) / 64 * 64;
+    p->T = d->horizon;
+    if (ilqr_dims_of(d, &p->dims) || lower_desc(c, *d, p->B, p->Bp, p->hdesc)) { delete p; return 1; }
+    const int T = p->T, NX = p->dims.n_x, NU = p->dims.n_u, NF = p->dims.n_f, Bp = p->Bp;
+    std::memset(&p->bufs, 0, sizeof(p->bufs));
+    Bufs& b = p->bufs;
+    int rc = 0;
+    rc |= dalloc(p, &p->ddesc, 1);
+    double *q0, *dq0, *U0, *tg;
+    for (int i = 0; i < 2; i++) { rc |= dalloc(p, &b.X[i], (size_t)T * NX * Bp); rc |= dalloc(p, &b.U[i], (size_t)(T - 1) * NU * Bp); }
+    rc |= dalloc(p, &U0, (size_t)(T - 1) * NU * Bp);
+    rc |= dalloc(p, &b.K, (size_t)(T - 1) * NU * NX * Bp);
+    rc |= dalloc(p, &b.D, (size_t)(T - 1) * NU * Bp);
+    rc |= dalloc(p, &q0, (size_t)DOF * Bp);
+    rc |= dalloc(p, &dq0, (size_t)DOF * Bp);
+    rc |= dalloc(p, &tg, (size_t)(d->n_kp > 0 ? d->n_kp : 1) * NF * Bp);
+    rc |= dalloc(p, &b.cost, Bp);
+    rc |= dalloc(p, &b.alpha, Bp);
+    rc |= dalloc(p, &b.cur, Bp);
+    rc |= dalloc(p, &b.active, Bp);
+    rc |= dalloc(p, &b.iters, Bp);
+    rc |= dalloc(p, &b.status, Bp);
+    if (rc) { ilqr_problem_destroy(p); return 1; }
+    b.U0 = U0; b.q0 = q0; b.dq0 = dq0; b.kp_tg = tg; b.desc = p->ddesc;
+    if (hipMemcpyAsync(p->ddesc, &p->hdesc, sizeof(DevDesc), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) {
+        ilqr_problem_destroy(p);
+        return fail(c, "descriptor upload failed");
+    }
+    *out = p;
+    return 0;
+}
+
+extern "C" void ilqr_problem_destroy(ilqr_problem* p) {
+    if (!p) return;
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipStreamSynchronize(p->ctx->stream);
+    for (void* q : p->allocs) (void)hipFree(q);
+    if (p->staging) (void)hipFree(p->staging);
+    batchcp_free(p->cp);
+    delete p;
+}
+
+// natural [B][rows] host or device array -> SoA [rows][Bp] device buffer
+static int upload(ilqr_problem* p, const double* src, bool src_is_dev, double* dst, int rows) {
+    ilqr_ctx* c = p->ctx;
+    const size_t n = (size_t)p->B * rows;
+    const double* dsrc = src;
+    if (!src_is_dev) {
+        if (ensure_staging(p, n)) return 1;
+        HIPCHK(c, hipMemcpyAsync(p->staging, src, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        dsrc = p->staging;
+    }
+    launch_to_soa(dsrc, dst, p->B, p->Bp, rows, c->stream);
+    HIPCHK(c, hipGetLastError());
+    if (!src_is_dev) HIPCHK(c, hipStreamSynchronize(c->stream));  // staging is reused; the host buffer may go away
+    return 0;
+}
+
+static int set_init_state(ilqr_problem* p, const double* q0, const double* dq0, bool dev) {
+    if (!p) return 1;
+    if (!q0) return fail(p->ctx, "q0 is required");
+    if (upload(p, q0, dev, (double*)p->bufs.q0, DOF)) return 1;
+    if (dq0) {
+        if (upload(p, dq0, dev, (double*)p->bufs.dq0, DOF)) return 1;
+    } else {
+        HIPCHK(p->ctx, hipMemsetAsync((void*)p->bufs.dq0, 0, sizeof(double) * DOF * p->Bp, p->ctx->stream));
+    }
+    p->has_state = true;
+    return 0;
+}
+extern "C" int ilqr_problem_set_init_state(ilqr_problem* p, const double* q0, const double* dq0) { return set_init_state(p, q0, dq0, false); }
+extern "C" int ilqr_problem_set_init_state_dev(ilqr_problem* p, const double* q0, const double* dq0) { return set_init_state(p, q0, dq0, true); }
+
+static int set_kp(ilqr_problem* p, int k, const double* tg, bool dev) {
+    if (!p) return 1;
+    if (k < 0 || k >= p->desc.n_kp || !tg) return fail(p->ctx, "bad keypoint index / null target");
+    return upload(p, tg, dev, (double*)p->bufs.kp_tg + (size_t)k * p->dims.n_f * p->Bp, p->dims.n_f);
+}
+extern "C" int ilqr_problem_set_keypoint_targets(ilqr_problem* p, int k, const double* tg) { return set_kp(p, k, tg, false); }
+extern "C" int ilqr_problem_set_keypoint_targets_dev(ilqr_problem* p, int k, const double* tg) { return set_kp(p, k, tg, true); }
+
+static int set_controls(ilqr_problem* p, const double* U0, bool dev) {
+    if (!p) return 1;
+    if (!U0) return fail(p->ctx, "U0 is required");
+    if (upload(p, U0, dev, (double*)p->bufs.U0, (p->T - 1) * p->dims.n_u)) return 1;
+    p->has_controls = true;
+    return 0;
+}
+extern "C" int ilqr_problem_set_controls(ilqr_problem* p, const double* U0) { return set_controls(p, U0, false); }
+extern "C" int ilqr_problem_set_controls_dev(ilqr_problem* p, const double* U0) { return set_controls(p, U0, true); }
+
+extern "C" int ilqr_problem_set_constraints(ilqr_problem* p, int m, int per_step, const double* A, const double* b, const double* lambda0) {
+    if (!p) return 1;
+    ilqr_ctx* c = p->ctx;
+    if (m <= 0 || !A || !b) return fail(c, "bad constraint arguments");
+    const int ns = p->dims.n_x + p->dims.n_u, T = p->T;
+    const size_t nk = per_step ? (size_t)(T - 1) : 1;
+    if (p->bufs.m != m || p->bufs.per_step != per_step || !p->conA) {
+        if (dalloc(p, &p->conA, nk * m * ns) || dalloc(p, &p->conb, nk * m)) return 1;
+        double *lam, *Is;
+        if (dalloc(p, &lam, (size_t)(T - 1) * m * p->Bp) || dalloc(p, &Is, (size_t)(T - 1) * m * p->Bp)) return 1;
+        p->bufs.lambda = lam;
+        p->bufs.Is = Is;
+        if (dalloc(p, &p->lambda0, (size_t)(T - 1) * m * p->Bp)) return 1;
+    }
+    HIPCHK(c, hipMemcpyAsync(p->conA, A, nk * m * ns * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(p->conb, b, nk * m * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    p->bufs.m = m; p->bufs.per_step = per_step; p->bufs.conA = p->conA; p->bufs.conb = p->conb;
+    if (lambda0) {
+        if (upload(p, lambda0, false, p->bufs.lambda, (T - 1) * m)) return 1;
+    } else {
+        HIPCHK(c, hipMemsetAsync(p->bufs.lambda, 0, sizeof(double) * (size_t)(T - 1) * m * p->Bp, c->stream));
+    }
+    HIPCHK(c, hipMemcpyAsync(p->lambda0, p->bufs.lambda, sizeof(double) * (size_t)(T - 1) * m * p->Bp, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
+extern "C" int ilqr_problem_reset_multipliers(ilqr_problem* p) {
+    if (!p) return 1;
+    if (p->bufs.m <= 0) return fail(p->ctx, "no constraints set");
+    HIPCHK(p->ctx, hipMemcpyAsync(p->bufs.lambda, p->lambda0, sizeof(double) * (size_t)(p->T - 1) * p->bufs.m * p->Bp,
+                                  hipMemcpyDeviceToDevice, p->ctx->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ solvers
+
+static int ensure_trace(ilqr_problem* p, int nb_iter) {
+    if (nb_iter > p->trace_iters) {
+        double *ct, *at;
+        if (dalloc(p, &ct, (size_t)nb_iter * p->Bp, false) || dalloc(p, &at, (size_t)nb_iter * p->Bp, false)) return 1;
+        p->bufs.cost_trace = ct;
+        p->bufs.alpha_trace = at;
+        p->trace_iters = nb_iter;
+    }
+    if (nb_iter > 0) {  // NaN-fill: entries after an instance's early stop stay NaN
+        HIPCHK(p->ctx, hipMemsetAsync(p->bufs.cost_trace, 0xFF, sizeof(double) * (size_t)nb_iter * p->Bp, p->ctx->stream));
+        HIPCHK(p->ctx, hipMemsetAsync(p->bufs.alpha_trace, 0xFF, sizeof(double) * (size_t)nb_iter * p->Bp, p->ctx->stream));
+    }
+    return 0;
+}
+
+static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double penalty, double scaling, int line_search, int early_stop) {
+    if (!p) return 1;
+    ilqr_ctx* c = p->ctx;
+    if (!p->has_state || !p->has_controls) return fail(c, "set_init_state and set_controls must be called before a solve");
+    if (nb_iter < 0) return fail(c, "nb_iter < 0");
+    if (al && (p->bufs.m <= 0 || lag <= 0)) return fail(c, "AL solve needs constraints (ilqr_problem_set_constraints) and lag_update_step > 0");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (ensure_trace(p, nb_iter)) return 1;
+    p->last_nb_iter = nb_iter;
+    FwdArgs f;
+    std::memset(&f, 0, sizeof(f));
+    f.line_search = line_search; f.early_stop = early_stop; f.nb_iter = nb_iter; f.penalty_roll = penalty;
+    {
+        ProfScope ps(c, ILQR_PROF_ROLLOUT);
+        launch_solver(p->desc.kind, p->desc.nb_deriv, KER_INIT, al, p->bufs, p->B, c->stream, f);
+    }
+    HIPCHK(c, hipGetLastError());
+    for (int it = 0; it < nb_iter; it++) {
+        {
+            ProfScope ps(c, ILQR_PROF_BACKWARD);
+            launch_solver(p->desc.kind, p->desc.nb_deriv, KER_BACKWARD, al, p->bufs, p->B, c->stream, f);
+        }
+        f.it = it;
+        f.penalty_roll = penalty;  // I_k is stored pre-multiplied by the penalty current at rollout time (AL-ILQR.cpp:190)
+        f.do_update = al && ((it + 1) % lag == 0);
+        if (f.do_update) penalty *= scaling;  // multipliers use the UPDATED penalty (AL-ILQR.cpp:203-205)
+        f.penalty_update = penalty;
+        {
+            ProfScope ps(c, ILQR_PROF_FORWARD);
+            launch_solver(p->desc.kind, p->desc.nb_deriv, KER_FORWARD, al, p->bufs, p->B, c->stream, f);
+        }
+        HIPCHK(c, hipGetLastError());
+    }
+    return 0;
+}
+
+extern "C" int ilqr_solve_recursive(ilqr_problem* p, int nb_iter, int line_search, int early_stop) {
+    return solve_riccati(p, false, nb_iter, 1, 0.0, 1.0, line_search, early_stop);
+}
+extern "C" int ilqr_solve_al(ilqr_problem* p, int nb_iter, int lag, double penalty, double scaling, int line_search, int early_stop) {
+    return solve_riccati(p, true, nb_iter, lag, penalty, scaling, line_search, early_stop);
+}
+
+extern "C" int ilqr_solve_batch_cp(ilqr_problem* p, const double* psi, int Kw, int nb_iter, int early_stop) {
+    if (!p) return 1;
+    ilqr_ctx* c = p->ctx;
+    if (!p->has_state || !p->has_controls) return fail(c, "set_init_state and set_controls must be called before a solve");
+    std::string err;
+    if (ensure_trace(p, nb_iter)) return 1;
+    p->last_nb_iter = nb_iter;
+    if (batchcp_solve(p->cp, p->hdesc, p->bufs, p->dims.n_x, p->dims.n_u, p->dims.n_f, p->dims.n_Q, psi, Kw, nb_iter, early_stop, c->stream, err))
+        return fail(c, err);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ results
+
+enum { GET_PLAIN, GET_CUR, GET_SCALED };
+static int download(ilqr_problem* p, int mode, const double* s0, const double* s1, double* dst, bool dst_is_dev, int rows) {
+    ilqr_ctx* c = p->ctx;
+    if (!dst) return fail(c, "null output pointer");
+    const size_t n = (size_t)p->B * rows;
+    double* ddst = dst;
+    if (!dst_is_dev) {
+        if (ensure_staging(p, n)) return 1;
+        ddst = p->staging;
+    }
+    if (mode == GET_CUR) launch_from_soa_cur(s0, s1, p->bufs.cur, ddst, p->B, p->Bp, rows, c->stream);
+    else if (mode == GET_SCALED) launch_from_soa_scaled(s0, p->bufs.alpha, p->bufs.iters, ddst, p->B, p->Bp, rows, c->stream);
+    else launch_from_soa(s0, ddst, p->B, p->Bp, rows, c->stream);
+    HIPCHK(c, hipGetLastError());
+    if (!dst_is_dev) {
+        HIPCHK(c, hipMemcpyAsync(dst, p->staging, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+extern "C" int ilqr_problem_get_X(ilqr_problem* p, double* X) { return p ? download(p, GET_CUR, p->bufs.X[0], p->bufs.X[1], X, false, p->T * p->dims.n_x) : 1; }
+extern "C" int ilqr_problem_get_U(ilqr_problem* p, double* U) { return p ? download(p, GET_CUR, p->bufs.U[0], p->bufs.U[1], U, false, (p->T - 1) * p->dims.n_u) : 1; }
+extern "C" int ilqr_problem_get_X_dev(ilqr_problem* p, double* X) { return p ? download(p, GET_CUR, p->bufs.X[0], p->bufs.X[1], X, true, p->T * p->dims.n_x) : 1; }
+extern "C" int ilqr_problem_get_U_dev(ilqr_problem* p, double* U) { return p ? download(p, GET_CUR, p->bufs.U[0], p->bufs.U[1], U, true, (p->T - 1) * p->dims.n_u) : 1; }
+extern "C" int ilqr_problem_get_K(ilqr_problem* p, double* K) { return p ? download(p, GET_PLAIN, p->bufs.K, nullptr, K, false, (p->T - 1) * p->dims.n_u * p->dims.n_x) : 1; }
+extern "C" int ilqr_problem_get_d(ilqr_problem* p, double* d) { return p ? download(p, GET_SCALED, p->bufs.D, nullptr, d, false, (p->T - 1) * p->dims.n_u) : 1; }
+extern "C" int ilqr_problem_get_cost(ilqr_problem* p, double* cost) { return p ? download(p, GET_PLAIN, p->bufs.cost, nullptr, cost, false, 1) : 1; }
+extern "C" int ilqr_problem_get_cost_dev(ilqr_problem* p, double* cost) { return p ? download(p, GET_PLAIN, p->bufs.cost, nullptr, cost, true, 1) : 1; }
+extern "C" int ilqr_problem_get_alpha(ilqr_problem* p, double* alpha) { return p ? download(p, GET_PLAIN, p->bufs.alpha, nullptr, alpha, false, 1) : 1; }
+extern "C" int ilqr_problem_get_lambda(ilqr_problem* p, double* lam) {
+    if (!p) return 1;
+    if (p->bufs.m <= 0) return fail(p->ctx, "no constraints set");
+    return download(p, GET_PLAIN, p->bufs.lambda, nullptr, lam, false, (p->T - 1) * p->bufs.m);
+}
+
+static int get_ints(ilqr_problem* p, const int* src, int* dst) {
+    if (!p) return 1;
+    if (!dst) return fail(p->ctx, "null output pointer");
+    HIPCHK(p->ctx, hipMemcpyAsync(dst, src, sizeof(int) * p->B, hipMemcpyDeviceToHost, p->ctx->stream));
+    HIPCHK(p->ctx, hipStreamSynchronize(p->ctx->stream));
+    return 0;
+}
+extern "C" int ilqr_problem_get_iters(ilqr_problem* p, int* iters) { return get_ints(p, p ? p->bufs.iters : nullptr, iters); }
+extern "C" int ilqr_problem_get_status(ilqr_problem* p, int* status) { return get_ints(p, p ? p->bufs.status : nullptr, status); }
+
+extern "C" int ilqr_problem_get_trace(ilqr_problem* p, double* ct, double* at, int nb_iter) {
+    if (!p) return 1;
+    if (nb_iter <= 0 || nb_iter > p->last_nb_iter) return fail(p->ctx, "nb_iter exceeds the last solve's iteration count");
+    if (ct && download(p, GET_PLAIN, p->bufs.cost_trace, nullptr, ct, false, nb_iter)) return 1;
+    if (at && download(p, GET_PLAIN, p->bufs.alpha_trace, nullptr, at, false, nb_iter)) return 1;
+    return 0;
+}
+
+extern "C" int ilqr_problem_get_fX(ilqr_problem* p, double* fX) {
+    if (!p) return 1;
+    ilqr_ctx* c = p->ctx;
+    if (!fX) return fail(c, "null output pointer");
+    const size_t n = (size_t)p->B * p->T * p->dims.n_f;
+    if (ensure_staging(p, n)) return 1;
+    {
+        ProfScope ps(c, ILQR_PROF_OTHER);
+        launch_fx_all(p->desc.kind, p->desc.nb_deriv, p->bufs, p->B, p->T, p->staging, c->stream);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(fX, p->staging, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ stand-alone FK
+
+extern "C" int ilqr_fk_batch(ilqr_ctx* c, const ilqr_problem_desc* d, int n, const double* q, double* pos, double* quat, double* jac) {
+    if (!c) return 1;
+    if (!d || n <= 0 || !q) return fail(c, "bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    DevDesc h;
+    std::memset(&h, 0, sizeof(h));
+    if (lower_chain(c, *d, h.chain)) return 1;
+    DevDesc* dd = nullptr;
+    double *dq = nullptr, *dp = nullptr, *dqt = nullptr, *dj = nullptr;
+    int rc = 0;
+    auto cleanup = [&]() { (void)hipFree(dd); (void)hipFree(dq); (void)hipFree(dp); (void)hipFree(dqt); (void)hipFree(dj); };
+#define FKCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); return fail(c, std::string(#call) + ": " + hipGetErrorString(e_)); } } while (0)
+    FKCHK(hipMalloc((void**)&dd, sizeof(DevDesc)));
+    FKCHK(hipMalloc((void**)&dq, sizeof(double) * n * DOF));
+    if (pos) FKCHK(hipMalloc((void**)&dp, sizeof(double) * n * 3));
+    if (quat) FKCHK(hipMalloc((void**)&dqt, sizeof(double) * n * 4));
+    if (jac) FKCHK(hipMalloc((void**)&dj, sizeof(double) * n * 6 * DOF));
+    FKCHK(hipMemcpyAsync(dd, &h, sizeof(DevDesc), hipMemcpyHostToDevice, c->stream));
+    FKCHK(hipMemcpyAsync(dq, q, sizeof(double) * n * DOF, hipMemcpyHostToDevice, c->stream));
+    launch_fk_batch(dd, n, dq, dp, dqt, dj, c->stream);
+    FKCHK(hipGetLastError());
+    if (pos) FKCHK(hipMemcpyAsync(pos, dp, sizeof(double) * n * 3, hipMemcpyDeviceToHost, c->stream));
+    if (quat) FKCHK(hipMemcpyAsync(quat, dqt, sizeof(double) * n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (jac) FKCHK(hipMemcpyAsync(jac, dj, sizeof(double) * n * 6 * DOF, hipMemcpyDeviceToHost, c->stream));
+    FKCHK(hipStreamSynchronize(c->stream));
+#undef FKCHK
+    cleanup();
+    return rc;
+}

@@ -1,0 +1,599 @@
+// ilqr_kernels.hip -- batched iLQR kernels for gfx950 (MI355X), fp64.
+//
+// v1 mapping: ONE LANE PER PROBLEM INSTANCE.  Trajectory/gain buffers are structure-of-arrays with the batch
+// innermost ([t][component][Bp]) so every load/store of a wave is one contiguous 512-byte segment; all the small
+// dense algebra of a timestep lives in that lane's registers.  The time recursion (rollout, Riccati sweep) is
+// sequential inside the lane; parallelism is across instances only.
+//
+// Reference behaviour restated (paths relative to ilqr_planner/ilqr_planner in the reference tree):
+//   initial rollout            src/solver/ILQRRecursive.cpp:27-56   (AL: src/solver/AL-ILQR.cpp:53-85)
+//   backward Riccati sweep     src/solver/ILQRRecursive.cpp:68-97   (AL terms: src/solver/AL-ILQR.cpp:110-134)
+//   forward pass + line search src/solver/ILQRRecursive.cpp:101-176 (AL: src/solver/AL-ILQR.cpp:149-227)
+// A_k, B_k are never stored: they are rebuilt from (x_k, u_k) exactly as forwardPass builds them.
+#include "ilqr_kernels.hpp"
+
+namespace ilqr {
+
+#define UNR _Pragma("unroll")
+#define AT(buf, row, b) (buf)[(size_t)(row) * (size_t)Bp + (size_t)(b)]
+
+// ------------------------------------------------------------------------------------------------ helpers
+
+template <class S>
+ILQR_DEV void load_vec(const double* buf, int row0, int n, int Bp, int b, double* out) {
+    for (int i = 0; i < n; i++) out[i] = AT(buf, row0 + i, b);
+}
+
+// AL_ILQR::constraints (AL-ILQR.cpp:21-44): g = A [x;u] - b ; I = 0 iff (g<0 && lambda==0) ; stored as penalty*I
+template <class S>
+ILQR_DEV double con_g(const Bufs& a, int k, int r, const double* x, const double* u) {
+    const int ns = S::NX + S::NU;
+    const double* Ar = a.conA + ((size_t)(a.per_step ? k : 0) * a.m + r) * ns;
+    double g = 0;
+    UNR for (int i = 0; i < S::NX; i++) g += Ar[i] * x[i];
+    UNR for (int i = 0; i < S::NU; i++) g += Ar[S::NX + i] * u[i];
+    return g - a.conb[(size_t)(a.per_step ? k : 0) * a.m + r];
+}
+
+// lx, lxx of a stage (System::cost_x / cost_xx, System.cpp:248-308).  P <- lxx, p <- lx.
+template <class S>
+ILQR_DEV void stage_derivs(const DevDesc& d, const Bufs& a, int b, const double* x, int kpi, double (*lxx)[S::NX], double* lx) {
+    constexpr int NX = S::NX, NQ = S::NQ, NF = S::NF;
+    const int Bp = d.Bp;
+    UNR for (int i = 0; i < NX; i++) {
+        lx[i] = 0;
+        UNR for (int j = 0; j < NX; j++) lxx[i][j] = 0;
+    }
+    if (kpi >= 0) {
+        double fxv[NF], J[6][DOF], e[NQ], tg[NF], Qe[NQ];
+        fx_of<S, true>(d, x, fxv, J);
+        UNR for (int i = 0; i < NF; i++) tg[i] = AT(a.kp_tg, kpi * NF + i, b);
+        kp_diff<S>(tg, fxv, e);
+        const double* Q = d.kp_Q[kpi];
+        UNR for (int i = 0; i < NQ; i++) {
+            double s = 0;
+            UNR for (int j = 0; j < NQ; j++) s += Q[i * NQ + j] * e[j];
+            Qe[i] = s;
+        }
+        // Jf (NQ x NX) = blkdiag(J, J) bordered by 1 for the time state; lx = -Jf^T Q e ; lxx = Jf^T Q Jf
+        UNR for (int blk = 0; blk < S::ND; blk++) {
+            UNR for (int c = 0; c < DOF; c++) {
+                double s = 0;
+                UNR for (int r = 0; r < 6; r++) s += J[r][c] * Qe[6 * blk + r];
+                lx[DOF * blk + c] += -1 * s;
+            }
+        }
+        if (S::TM) lx[NX - 1] += -1 * Qe[NQ - 1];
+        // JtQ[c][r'] for c in block blk: sum_r J[r][c%7] Q[6 blk + r][r']
+        UNR for (int blk = 0; blk < S::ND; blk++) {
+            UNR for (int c = 0; c < DOF; c++) {
+                double jq[NQ];
+                UNR for (int rp = 0; rp < NQ; rp++) {
+                    double s = 0;
+                    UNR for (int r = 0; r < 6; r++) s += J[r][c] * Q[(6 * blk + r) * NQ + rp];
+                    jq[rp] = s;
+                }
+                UNR for (int blk2 = 0; blk2 < S::ND; blk2++) {
+                    UNR for (int c2 = 0; c2 < DOF; c2++) {
+                        double s = 0;
+                        UNR for (int r = 0; r < 6; r++) s += jq[6 * blk2 + r] * J[r][c2];
+                        lxx[DOF * blk + c][DOF * blk2 + c2] += s;
+                    }
+                }
+                if (S::TM) lxx[DOF * blk + c][NX - 1] += jq[NQ - 1];
+            }
+        }
+        if (S::TM) {
+            UNR for (int blk2 = 0; blk2 < S::ND; blk2++) {
+                UNR for (int c2 = 0; c2 < DOF; c2++) {
+                    double s = 0;
+                    UNR for (int r = 0; r < 6; r++) s += Q[(NQ - 1) * NQ + 6 * blk2 + r] * J[r][c2];
+                    lxx[NX - 1][DOF * blk2 + c2] += s;
+                }
+            }
+            lxx[NX - 1][NX - 1] += Q[(NQ - 1) * NQ + NQ - 1];
+        }
+    }
+    if (d.limits_set) {
+        UNR for (int i = 0; i < NX; i++) {
+            if (d.lw[i] != 0) {
+                double qv = 0, L = 0;
+                if (x[i] > d.smax[i]) { qv = d.smax[i] - x[i]; L = d.penalty; }
+                else if (x[i] < d.smin[i]) { qv = d.smin[i] - x[i]; L = d.penalty; }
+                lx[i] += -L * qv;
+                lxx[i][i] += L * L;
+            }
+        }
+    }
+}
+
+// Eigen MatrixXd::inverse() (PartialPivLU + solve against identity), fully unrolled, no dynamic indexing.
+template <int N>
+ILQR_DEV void inverse_lu(double (*M)[N], double (*Inv)[N]) {
+    int piv[N];
+    UNR for (int i = 0; i < N; i++) piv[i] = i;
+    UNR for (int k = 0; k < N; k++) {
+        // pivot search: first row with the largest |M[r][k]|, r >= k
+        double best = fabs(M[k][k]);
+        int r = k;
+        UNR for (int i = k + 1; i < N; i++) {
+            double v = fabs(M[i][k]);
+            if (v > best) { best = v; r = i; }
+        }
+        UNR for (int i = k + 1; i < N; i++) {
+            bool sw = (r == i);
+            UNR for (int j = 0; j < N; j++) {
+                double t0 = M[k][j], t1 = M[i][j];
+                M[k][j] = sw ? t1 : t0;
+                M[i][j] = sw ? t0 : t1;
+            }
+            int p0 = piv[k], p1 = piv[i];
+            piv[k] = sw ? p1 : p0;
+            piv[i] = sw ? p0 : p1;
+        }
+        double pv = M[k][k];
+        UNR for (int i = k + 1; i < N; i++) {
+            M[i][k] /= pv;
+            double f = M[i][k];
+            UNR for (int j = k + 1; j < N; j++) M[i][j] -= f * M[k][j];
+        }
+    }
+    UNR for (int c = 0; c < N; c++) {
+        UNR for (int i = 0; i < N; i++) {
+            double s = (piv[i] == c) ? 1.0 : 0.0;
+            UNR for (int j = 0; j < i; j++) s -= M[i][j] * Inv[j][c];
+            Inv[i][c] = s;
+        }
+        UNR for (int i = N - 1; i >= 0; i--) {
+            double s = Inv[i][c];
+            UNR for (int j = i + 1; j < N; j++) s -= M[i][j] * Inv[j][c];
+            Inv[i][c] = s / M[i][i];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ rollout pieces
+
+// stage cost l(x,u,k) (System::cost): task part only at keypoint steps, limits always
+template <class S>
+ILQR_DEV double stage_cost(const DevDesc& d, const Bufs& a, int b, int kpi, const double* x, const double* u) {
+    const int Bp = d.Bp;
+    double c = 0;
+    if (kpi >= 0) {
+        double tg[S::NF];
+        UNR for (int i = 0; i < S::NF; i++) tg[i] = AT(a.kp_tg, kpi * S::NF + i, b);
+        c += kp_cost<S>(d, kpi, tg, x, u);
+    }
+    if (d.limits_set) c += limit_cost<S>(d, x);
+    return c;
+}
+
+template <class S>
+ILQR_DEV void init_state(const DevDesc& d, const Bufs& a, int b, double* x) {
+    const int Bp = d.Bp;
+    UNR for (int i = 0; i < DOF; i++) x[i] = AT(a.q0, i, b);
+    if (S::ND == 2) { UNR for (int i = 0; i < DOF; i++) x[DOF + i] = AT(a.dq0, i, b); }
+    if (S::TM) x[S::NX - 1] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------ kernels
+
+// Initial rollout from U0 (ILQRRecursive.cpp:27-56): X, cost0; resets the per-instance solve state.
+template <class S, bool AL>
+__global__ __launch_bounds__(64) void k_init_rollout(Bufs a, double penalty) {
+    constexpr int NX = S::NX, NU = S::NU;
+    const DevDesc& d = *a.desc;
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= d.B) return;
+    const int Bp = d.Bp, T = d.T;
+    double x[NX], u[NU], xn[NX];
+    init_state<S>(d, a, b, x);
+    double cost = 0;
+    int kpi = 0;
+    double* X = a.X[0];
+    double* U = a.U[0];
+    for (int k = 0; k < T - 1; k++) {
+        UNR for (int i = 0; i < NX; i++) AT(X, k * NX + i, b) = x[i];
+        UNR for (int i = 0; i < NU; i++) { u[i] = AT(a.U0, k * NU + i, b); AT(U, k * NU + i, b) = u[i]; }
+        if (AL) {
+            for (int r = 0; r < a.m; r++) {
+                double g = con_g<S>(a, k, r, x, u);
+                double lam = AT(a.lambda, k * a.m + r, b);
+                AT(a.Is, k * a.m + r, b) = penalty * ((g < 0 && lam == 0) ? 0.0 : 1.0);
+            }
+        }
+        const bool iskp = (kpi < d.n_kp && d.kp_t[kpi] == k);
+        cost += stage_cost<S>(d, a, b, iskp ? kpi : -1, x, u);
+        if (iskp) kpi++;
+        dyn_step<S>(d, x, u, xn);
+        UNR for (int i = 0; i < NX; i++) x[i] = xn[i];
+    }
+    UNR for (int i = 0; i < NX; i++) AT(X, (T - 1) * NX + i, b) = x[i];
+    {
+        const bool iskp = (kpi < d.n_kp && d.kp_t[kpi] == T - 1);
+        double zu[NU];
+        UNR for (int i = 0; i < NU; i++) zu[i] = 0;
+        cost += stage_cost<S>(d, a, b, iskp ? kpi : -1, x, zu);
+    }
+    a.cost[b] = cost;
+    a.alpha[b] = 1.0;
+    a.cur[b] = 0;
+    a.active[b] = 1;
+    a.iters[b] = 0;
+    a.status[b] = isfinite(cost) ? 0 : 1;
+}
+
+// Backward Riccati sweep (ILQRRecursive.cpp:68-97): writes K_k, d_k for k = T-2..0.
+template <class S, bool AL>
+__global__ __launch_bounds__(64) void k_backward(Bufs a) {
+    constexpr int NX = S::NX, NU = S::NU, ND = S::ND, TM = S::TM;
+    const DevDesc& d = *a.desc;
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= d.B) return;
+    if (!a.active[b]) return;
+    const int Bp = d.Bp, T = d.T;
+    const int cur = a.cur[b];
+    const double* X = a.X[cur];
+    const double* U = a.U[cur];
+    double P[NX][NX], p[NX], x[NX], u[NU];
+    int kpi = d.n_kp - 1;
+    UNR for (int i = 0; i < NX; i++) x[i] = AT(X, (T - 1) * NX + i, b);
+    {
+        const bool iskp = (kpi >= 0 && d.kp_t[kpi] == T - 1);
+        stage_derivs<S>(d, a, b, x, iskp ? kpi : -1, P, p);
+        if (iskp) kpi--;
+    }
+    for (int k = T - 2; k >= 0; k--) {
+        UNR for (int i = 0; i < NX; i++) x[i] = AT(X, k * NX + i, b);
+        UNR for (int i = 0; i < NU; i++) u[i] = AT(U, k * NU + i, b);
+        const double dts = TM ? u[NU - 1] : 0.0;
+        const double dt = TM ? dts * dts : d.dt;
+        const double hdt2 = dt * dt / 2;
+        // last column of B for time systems (PosOrnTimePlannerSys.cpp:161-162,176)
+        double bc[NX];
+        if (TM) {
+            if (ND == 1) {
+                UNR for (int i = 0; i < DOF; i++) bc[i] = 2 * dts * u[i];
+            } else {
+                UNR for (int i = 0; i < DOF; i++) {
+                    double dqn = x[DOF + i] + dt * u[i];  // velocity AFTER the step
+                    bc[i] = 2 * dts * dqn + 2 * dts * dts * dts * u[i];
+                    bc[DOF + i] = 2 * dts * u[i];
+                }
+            }
+            bc[NX - 1] = 2 * dts;
+        }
+        double lxx[NX][NX], lx[NX];
+        {
+            const bool iskp = (kpi >= 0 && d.kp_t[kpi] == k);
+            stage_derivs<S>(d, a, b, x, iskp ? kpi : -1, lxx, lx);
+            if (iskp) kpi--;
+        }
+        // BtP = B^T P (NU x NX), AtP = A^T P (NX x NX)
+        double BtP[NU][NX], AtP[NX][NX];
+        UNR for (int i = 0; i < DOF; i++)
+            UNR for (int j = 0; j < NX; j++)
+                BtP[i][j] = (ND == 1) ? dt * P[i][j] : hdt2 * P[i][j] + dt * P[DOF + i][j];
+        if (TM) {
+            UNR for (int j = 0; j < NX; j++) {
+                double s = 0;
+                UNR for (int l = 0; l < NX; l++) s += bc[l] * P[l][j];
+                BtP[NU - 1][j] = s;
+            }
+        }
+        UNR for (int i = 0; i < NX; i++)
+            UNR for (int j = 0; j < NX; j++)
+                AtP[i][j] = (ND == 2 && i >= DOF && i < 2 * DOF) ? dt * P[i - DOF][j] + P[i][j] : P[i][j];
+        // Qux = BtP A ; Quu = R + BtP B ; Qxx = lxx + AtP A ; Qxu = AtP B ; Qu = R u + B^T p ; Qx = lx + A^T p
+        double Qux[NU][NX], Quu[NU][NU], Qxx[NX][NX], Qxu[NX][NU], Qu[NU], Qx[NX];
+        UNR for (int i = 0; i < NU; i++) {
+            UNR for (int j = 0; j < NX; j++)
+                Qux[i][j] = (ND == 2 && j >= DOF && j < 2 * DOF) ? BtP[i][j - DOF] * dt + BtP[i][j] : BtP[i][j];
+            UNR for (int j = 0; j < DOF; j++)
+                Quu[i][j] = (ND == 1) ? BtP[i][j] * dt : BtP[i][j] * hdt2 + BtP[i][DOF + j] * dt;
+            if (TM) {
+                double s = 0;
+                UNR for (int l = 0; l < NX; l++) s += BtP[i][l] * bc[l];
+                Quu[i][NU - 1] = s;
+            }
+            Quu[i][i] = d.R_diag[i] + Quu[i][i];
+        }
+        UNR for (int i = 0; i < NX; i++) {
+            UNR for (int j = 0; j < NX; j++) {
+                double v = (ND == 2 && j >= DOF && j < 2 * DOF) ? AtP[i][j - DOF] * dt + AtP[i][j] : AtP[i][j];
+                Qxx[i][j] = lxx[i][j] + v;
+            }
+            UNR for (int j = 0; j < DOF; j++)
+                Qxu[i][j] = (ND == 1) ? AtP[i][j] * dt : AtP[i][j] * hdt2 + AtP[i][DOF + j] * dt;
+            if (TM) {
+                double s = 0;
+                UNR for (int l = 0; l < NX; l++) s += AtP[i][l] * bc[l];
+                Qxu[i][NU - 1] = s;
+            }
+        }
+        UNR for (int i = 0; i < DOF; i++) {
+            double v = (ND == 1) ? dt * p[i] : hdt2 * p[i] + dt * p[DOF + i];
+            Qu[i] = d.R_diag[i] * u[i] + v;
+        }
+        if (TM) {
+            double s = 0;
+            UNR for (int l = 0; l < NX; l++) s += bc[l] * p[l];
+            Qu[NU - 1] = d.R_diag[NU - 1] * u[NU - 1] + s;
+        }
+        UNR for (int i = 0; i < NX; i++) {
+            double v = (ND == 2 && i >= DOF && i < 2 * DOF) ? dt * p[i - DOF] + p[i] : p[i];
+            Qx[i] = lx[i] + v;
+        }
+        if (AL) {  // AL-ILQR.cpp:110-134: c_u' I c_x etc., lambda + I c
+            const int ns = NX + NU;
+            for (int r = 0; r < a.m; r++) {
+                const double* Ar = a.conA + ((size_t)(a.per_step ? k : 0) * a.m + r) * ns;
+                const double Ik = AT(a.Is, k * a.m + r, b);
+                const double lam = AT(a.lambda, k * a.m + r, b);
+                const double g = con_g<S>(a, k, r, x, u);
+                const double wv = lam + Ik * g;
+                UNR for (int i = 0; i < NU; i++) {
+                    const double au = Ar[NX + i];
+                    UNR for (int j = 0; j < NX; j++) Qux[i][j] += au * Ik * Ar[j];
+                    UNR for (int j = 0; j < NU; j++) Quu[i][j] += au * Ik * Ar[NX + j];
+                    Qu[i] += au * wv;
+                }
+                UNR for (int i = 0; i < NX; i++) {
+                    const double ax = Ar[i];
+                    UNR for (int j = 0; j < NX; j++) Qxx[i][j] += ax * Ik * Ar[j];
+                    UNR for (int j = 0; j < NU; j++) Qxu[i][j] += ax * Ik * Ar[NX + j];
+                    Qx[i] += ax * wv;
+                }
+            }
+        }
+        // Quu_inv = -(Quu + reg I)^-1 ; K = Quu_inv Qux ; d = Quu_inv Qu
+        double Mr[NU][NU], Qi[NU][NU];
+        UNR for (int i = 0; i < NU; i++)
+            UNR for (int j = 0; j < NU; j++) Mr[i][j] = Quu[i][j] + ((i == j) ? d.reg : 0.0);
+        inverse_lu<NU>(Mr, Qi);
+        double Kk[NU][NX], dk[NU];
+        UNR for (int i = 0; i < NU; i++) {
+            UNR for (int j = 0; j < NX; j++) {
+                double s = 0;
+                UNR for (int l = 0; l < NU; l++) s += (-1 * Qi[i][l]) * Qux[l][j];
+                Kk[i][j] = s;
+                AT(a.K, k * NU * NX + i * NX + j, b) = s;
+            }
+            double s = 0;
+            UNR for (int l = 0; l < NU; l++) s += (-1 * Qi[i][l]) * Qu[l];
+            dk[i] = s;
+            AT(a.D, k * NU + i, b) = s;
+        }
+        // P = Qxx + K'QuuK + K'Qux + QxuK ; p = Qx + K'Quu d + K'Qu + Qxu d   (un-regularised Quu)
+        double KtQuu[NX][NU];
+        UNR for (int i = 0; i < NX; i++)
+            UNR for (int j = 0; j < NU; j++) {
+                double s = 0;
+                UNR for (int l = 0; l < NU; l++) s += Kk[l][i] * Quu[l][j];
+                KtQuu[i][j] = s;
+            }
+        UNR for (int i = 0; i < NX; i++) {
+            UNR for (int j = 0; j < NX; j++) {
+                double t1 = 0, t2 = 0, t3 = 0;
+                UNR for (int l = 0; l < NU; l++) {
+                    t1 += KtQuu[i][l] * Kk[l][j];
+                    t2 += Kk[l][i] * Qux[l][j];
+                    t3 += Qxu[i][l] * Kk[l][j];
+                }
+                P[i][j] = ((Qxx[i][j] + t1) + t2) + t3;
+            }
+            double v1 = 0, v2 = 0, v3 = 0;
+            UNR for (int l = 0; l < NU; l++) {
+                v1 += KtQuu[i][l] * dk[l];
+                v2 += Kk[l][i] * Qu[l];
+                v3 += Qxu[i][l] * dk[l];
+            }
+            p[i] = ((Qx[i] + v1) + v2) + v3;
+        }
+    }
+}
+
+// Forward pass with step-halving line search (ILQRRecursive.cpp:101-176).  Each trial re-rolls the whole horizon
+// and overwrites the instance's inactive trajectory buffer; the last trial executed is the accepted one.
+template <class S, bool AL>
+__global__ __launch_bounds__(64) void k_forward(Bufs a, int it, int line_search, int early_stop, double penalty_roll,
+                                                double penalty_update, int do_update, int nb_iter) {
+    constexpr int NX = S::NX, NU = S::NU;
+    const DevDesc& d = *a.desc;
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= d.B) return;
+    if (!a.active[b]) return;
+    const int Bp = d.Bp, T = d.T;
+    const int cur = a.cur[b];
+    const double* X = a.X[cur];
+    const double* U = a.U[cur];
+    double* Xn = a.X[1 - cur];
+    double* Un = a.U[1 - cur];
+    const double cost0 = a.cost[b];
+    double alpha = 2, newCost = 0, dun = 0;
+    do {
+        alpha /= 2.0;
+        double x[NX], xn[NX], u[NU];
+        init_state<S>(d, a, b, x);
+        dun = 0;
+        newCost = 0;
+        int kpi = 0;
+        for (int k = 0; k < T - 1; k++) {
+            double dx[NX];
+            UNR for (int i = 0; i < NX; i++) dx[i] = x[i] - AT(X, k * NX + i, b);
+            double n2 = 0;
+            UNR for (int i = 0; i < NU; i++) {
+                double s = 0;
+                UNR for (int j = 0; j < NX; j++) s += AT(a.K, k * NU * NX + i * NX + j, b) * dx[j];
+                double du = s + alpha * AT(a.D, k * NU + i, b);
+                n2 += du * du;
+                u[i] = AT(U, k * NU + i, b) + du;
+            }
+            dun += sqrt(n2);  // accumulates ||du||, not ||du||^2 (ILQRRecursive.cpp:132)
+            UNR for (int i = 0; i < NX; i++) AT(Xn, k * NX + i, b) = x[i];
+            UNR for (int i = 0; i < NU; i++) AT(Un, k * NU + i, b) = u[i];
+            if (AL) {
+                for (int r = 0; r < a.m; r++) {
+                    double g = con_g<S>(a, k, r, x, u);
+                    double lam = AT(a.lambda, k * a.m + r, b);
+                    AT(a.Is, k * a.m + r, b) = penalty_roll * ((g < 0 && lam == 0) ? 0.0 : 1.0);
+                }
+            }
+            const bool iskp = (kpi < d.n_kp && d.kp_t[kpi] == k);
+            newCost += stage_cost<S>(d, a, b, iskp ? kpi : -1, x, u);
+            if (iskp) kpi++;
+            dyn_step<S>(d, x, u, xn);
+            UNR for (int i = 0; i < NX; i++) x[i] = xn[i];
+        }
+        UNR for (int i = 0; i < NX; i++) AT(Xn, (T - 1) * NX + i, b) = x[i];
+        {
+            const bool iskp = (kpi < d.n_kp && d.kp_t[kpi] == T - 1);
+            double zu[NU];
+            UNR for (int i = 0; i < NU; i++) zu[i] = 0;
+            newCost += stage_cost<S>(d, a, b, iskp ? kpi : -1, x, zu);
+        }
+    } while (((newCost >= cost0) || isnan(newCost)) && alpha > d.alpha_floor && line_search);
+
+    if (AL && do_update) {  // multiplier update with the UPDATED penalty, on the accepted trajectory (AL-ILQR.cpp:202-208)
+        for (int k = 0; k < T - 1; k++) {
+            double x[NX], u[NU];
+            UNR for (int i = 0; i < NX; i++) x[i] = AT(Xn, k * NX + i, b);
+            UNR for (int i = 0; i < NU; i++) u[i] = AT(Un, k * NU + i, b);
+            for (int r = 0; r < a.m; r++) {
+                double g = con_g<S>(a, k, r, x, u);
+                double v = AT(a.lambda, k * a.m + r, b) + penalty_update * g;
+                AT(a.lambda, k * a.m + r, b) = v > 0 ? v : 0;
+            }
+        }
+    }
+    // accept unconditionally (ILQRRecursive.cpp:157-162)
+    a.cost[b] = newCost;
+    a.alpha[b] = alpha;
+    a.cur[b] = 1 - cur;
+    a.iters[b] = it + 1;
+    a.status[b] = (isfinite(newCost) ? 0 : 1) | ((alpha <= d.alpha_floor) ? 2 : 0);
+    if (a.cost_trace) {
+        a.cost_trace[(size_t)it * Bp + b] = newCost;
+        a.alpha_trace[(size_t)it * Bp + b] = alpha;
+    }
+    bool stop = early_stop && (alpha * sqrt(dun) < d.stop_tol);
+    if (!AL) stop = stop && (newCost < 1e-3);  // ILQRRecursive.cpp:174 vs AL-ILQR.cpp:225
+    if (stop) a.active[b] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------ gather / scatter
+
+// natural [B][rows] (host/ABI layout) <-> device [rows][Bp]
+__global__ void k_to_soa(const double* __restrict__ src, double* __restrict__ dst, int B, int Bp, int rows) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (b < B) dst[(size_t)r * Bp + b] = src[(size_t)b * rows + r];
+}
+__global__ void k_from_soa(const double* __restrict__ src, double* __restrict__ dst, int B, int Bp, int rows) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (b < B) dst[(size_t)b * rows + r] = src[(size_t)r * Bp + b];
+}
+// same, selecting each instance's current trajectory buffer
+__global__ void k_from_soa_cur(const double* __restrict__ s0, const double* __restrict__ s1, const int* __restrict__ cur,
+                               double* __restrict__ dst, int B, int Bp, int rows) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (b < B) dst[(size_t)b * rows + r] = (cur[b] ? s1 : s0)[(size_t)r * Bp + b];
+}
+// returned ds are scaled by the accepted alpha (ILQRRecursive.cpp:128,144,162)
+__global__ void k_from_soa_scaled(const double* __restrict__ src, const double* __restrict__ alpha, const int* __restrict__ iters,
+                                  double* __restrict__ dst, int B, int Bp, int rows) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (b < B) dst[(size_t)b * rows + r] = (iters[b] > 0 ? alpha[b] : 1.0) * src[(size_t)r * Bp + b];
+}
+
+// f(X) for every (instance, timestep): one lane per pair (tuple<1> of ILQRRecursive::solve)
+template <class S>
+__global__ void k_fx_all(Bufs a, double* __restrict__ out /* natural [B][T][NF] */) {
+    const DevDesc& d = *a.desc;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = blockIdx.y;
+    if (b >= d.B) return;
+    const int Bp = d.Bp;
+    const double* X = a.X[a.cur[b]];
+    double x[S::NX], fxv[S::NF];
+    UNR for (int i = 0; i < S::NX; i++) x[i] = AT(X, t * S::NX + i, b);
+    fx_of<S, false>(d, x, fxv, nullptr);
+    UNR for (int i = 0; i < S::NF; i++) out[((size_t)b * d.T + t) * S::NF + i] = fxv[i];
+}
+
+// stand-alone batched FK (KDLRobot::updateKinematics), natural layouts
+__global__ void k_fk_batch(const DevDesc* dd, int n, const double* __restrict__ q, double* __restrict__ pos, double* __restrict__ quat,
+                           double* __restrict__ jac) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double qv[DOF], p[3], qt[4], J[6][DOF];
+    UNR for (int j = 0; j < DOF; j++) qv[j] = q[(size_t)i * DOF + j];
+    fk<true>(dd->chain, qv, p, qt, J);
+    if (pos) { UNR for (int j = 0; j < 3; j++) pos[(size_t)i * 3 + j] = p[j]; }
+    if (quat) { UNR for (int j = 0; j < 4; j++) quat[(size_t)i * 4 + j] = qt[j]; }
+    if (jac) {
+        UNR for (int r = 0; r < 6; r++)
+            UNR for (int j = 0; j < DOF; j++) jac[((size_t)i * 6 + r) * DOF + j] = J[r][j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+
+template <class S>
+static void launch_solver_kernel(int which, bool al, const Bufs& a, int B, hipStream_t st, const FwdArgs& f) {
+    const dim3 grid((B + 63) / 64), block(64);
+    switch (which) {
+        case KER_INIT:
+            if (al) hipLaunchKernelGGL((k_init_rollout<S, true>), grid, block, 0, st, a, f.penalty_roll);
+            else hipLaunchKernelGGL((k_init_rollout<S, false>), grid, block, 0, st, a, f.penalty_roll);
+            break;
+        case KER_BACKWARD:
+            if (al) hipLaunchKernelGGL((k_backward<S, true>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((k_backward<S, false>), grid, block, 0, st, a);
+            break;
+        case KER_FORWARD:
+            if (al)
+                hipLaunchKernelGGL((k_forward<S, true>), grid, block, 0, st, a, f.it, f.line_search, f.early_stop, f.penalty_roll,
+                                   f.penalty_update, f.do_update, f.nb_iter);
+            else
+                hipLaunchKernelGGL((k_forward<S, false>), grid, block, 0, st, a, f.it, f.line_search, f.early_stop, f.penalty_roll,
+                                   f.penalty_update, f.do_update, f.nb_iter);
+            break;
+    }
+}
+
+void launch_solver(int kind, int nd, int which, bool al, const Bufs& a, int B, hipStream_t st, const FwdArgs& f) {
+    if (kind == 0 && nd == 1) launch_solver_kernel<Sys<0, 1>>(which, al, a, B, st, f);
+    else if (kind == 0 && nd == 2) launch_solver_kernel<Sys<0, 2>>(which, al, a, B, st, f);
+    else if (kind == 1 && nd == 1) launch_solver_kernel<Sys<1, 1>>(which, al, a, B, st, f);
+    else launch_solver_kernel<Sys<1, 2>>(which, al, a, B, st, f);
+}
+
+void launch_fx_all(int kind, int nd, const Bufs& a, int B, int T, double* out, hipStream_t st) {
+    const dim3 grid((B + 63) / 64, T), block(64);
+    if (kind == 0 && nd == 1) hipLaunchKernelGGL((k_fx_all<Sys<0, 1>>), grid, block, 0, st, a, out);
+    else if (kind == 0 && nd == 2) hipLaunchKernelGGL((k_fx_all<Sys<0, 2>>), grid, block, 0, st, a, out);
+    else if (kind == 1 && nd == 1) hipLaunchKernelGGL((k_fx_all<Sys<1, 1>>), grid, block, 0, st, a, out);
+    else hipLaunchKernelGGL((k_fx_all<Sys<1, 2>>), grid, block, 0, st, a, out);
+}
+
+void launch_to_soa(const double* src, double* dst, int B, int Bp, int rows, hipStream_t st) {
+    hipLaunchKernelGGL(k_to_soa, dim3((B + 255) / 256, rows), dim3(256), 0, st, src, dst, B, Bp, rows);
+}
+void launch_from_soa(const double* src, double* dst, int B, int Bp, int rows, hipStream_t st) {
+    hipLaunchKernelGGL(k_from_soa, dim3((B + 255) / 256, rows), dim3(256), 0, st, src, dst, B, Bp, rows);
+}
+void launch_from_soa_cur(const double* s0, const double* s1, const int* cur, double* dst, int B, int Bp, int rows, hipStream_t st) {
+    hipLaunchKernelGGL(k_from_soa_cur, dim3((B + 255) / 256, rows), dim3(256), 0, st, s0, s1, cur, dst, B, Bp, rows);
+}
+void launch_from_soa_scaled(const double* src, const double* alpha, const int* iters, double* dst, int B, int Bp, int rows, hipStream_t st) {
+    hipLaunchKernelGGL(k_from_soa_scaled, dim3((B + 255) / 256, rows), dim3(256), 0, st, src, alpha, iters, dst, B, Bp, rows);
+}
+void launch_fk_batch(const DevDesc* dd, int n, const double* q, double* pos, double* quat, double* jac, hipStream_t st) {
+    hipLaunchKernelGGL(k_fk_batch, dim3((n + 63) / 64), dim3(64), 0, st, dd, n, q, pos, quat, jac);
+}
+
+}  // namespace ilqr

@@ -1,0 +1,51 @@
+// ilqr_kernels.hpp -- device buffer table + kernel launchers shared by ilqr_kernels.hip and ilqr_capi.cpp
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "ilqr_device.hpp"
+
+namespace ilqr {
+
+// All trajectory-like buffers are [row][Bp] with the (padded) batch innermost; row = t * DIM + component.
+struct Bufs {
+    const DevDesc* desc;
+    double* X[2];  // [T][NX][Bp]   double-buffered; cur[b] says which one holds instance b's accepted trajectory
+    double* U[2];  // [T-1][NU][Bp]
+    const double* U0;  // [T-1][NU][Bp]
+    double* K;     // [T-1][NU*NX][Bp]
+    double* D;     // [T-1][NU][Bp]
+    const double* q0;   // [DOF][Bp]
+    const double* dq0;  // [DOF][Bp]
+    const double* kp_tg;  // [n_kp][NF][Bp]
+    double* cost;   // [Bp]
+    double* alpha;  // [Bp]
+    int* cur;
+    int* active;
+    int* iters;
+    int* status;
+    double* cost_trace;   // [nb_iter][Bp] or null
+    double* alpha_trace;  // [nb_iter][Bp] or null
+    // augmented Lagrangian (shared constraint rows, per-instance multipliers)
+    int m, per_step;
+    const double* conA;  // [T-1 or 1][m][NX+NU]
+    const double* conb;  // [T-1 or 1][m]
+    double* lambda;      // [T-1][m][Bp]
+    double* Is;          // [T-1][m][Bp]  penalty * active-set mask at rollout time
+};
+
+struct FwdArgs {
+    int it, line_search, early_stop, do_update, nb_iter;
+    double penalty_roll, penalty_update;
+};
+
+enum { KER_INIT = 0, KER_BACKWARD = 1, KER_FORWARD = 2 };
+
+void launch_solver(int kind, int nd, int which, bool al, const Bufs& a, int B, hipStream_t st, const FwdArgs& f);
+void launch_fx_all(int kind, int nd, const Bufs& a, int B, int T, double* out, hipStream_t st);
+void launch_to_soa(const double* src, double* dst, int B, int Bp, int rows, hipStream_t st);
+void launch_from_soa(const double* src, double* dst, int B, int Bp, int rows, hipStream_t st);
+void launch_from_soa_cur(const double* s0, const double* s1, const int* cur, double* dst, int B, int Bp, int rows, hipStream_t st);
+void launch_from_soa_scaled(const double* src, const double* alpha, const int* iters, double* dst, int B, int Bp, int rows, hipStream_t st);
+void launch_fk_batch(const DevDesc* dd, int n, const double* q, double* pos, double* quat, double* jac, hipStream_t st);
+
+}  // namespace ilqr

@@ -1,0 +1,112 @@
+"""Seeded synthetic problem batches for the BASELINE.json configs.
+
+Targets are FK(q_rand) for q_rand ~ U(joint limits), evaluated with the library's own batched FK kernel, so that
+every instance is reachable.  Nothing here touches the oracle or the reference tree.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from . import capi
+
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+Q0_TUT = np.array([0.62991112, -0.2329776, -0.01423721, -1.70254115, 0.06251303, 1.50592777, 0.71771416])
+
+
+def panda_urdf_text() -> str:
+    return open(os.path.join(_DATA, "panda_chain.urdf")).read()
+
+
+def panda_chain(tool_rpy=None, tool_xyz=None):
+    return capi.chain_from_urdf(panda_urdf_text(), "panda_link0", "panda_tip", tool_rpy, tool_xyz)
+
+
+def config(name: str):
+    """Static part of a BASELINE config: kind, nb_deriv, T, dt, B, seed, precision diagonals, keypoint times."""
+    P = [1, 1, 1, .1, .1, .1]
+    V = [1, 1, 1, .1, .1, .1]
+    cfgs = {
+        # C2: "pos-only" = zero orientation precision (POS_ORN_MULTI_SYS.ipynb cell 12)
+        "C2": dict(kind=capi.SYS_POS_ORN, nb_deriv=1, T=100, dt=0.1, B=256, seed=1, Qdiag=[[1, 1, 1, 0, 0, 0]] * 2, solver="recursive", nb_iter=20),
+        # C3: AL-iLQR with the tutorial's single row q_6 <= 2.0 (penalty .25, scaling 1.1, update every 5)
+        "C3": dict(kind=capi.SYS_POS_ORN, nb_deriv=1, T=200, dt=0.05, B=4096, seed=2, Qdiag=[P, P], solver="al", nb_iter=20,
+                   al=dict(row=5, bound=2.0, penalty=0.25, scaling=1.1, lag=5)),
+        "C3r": dict(kind=capi.SYS_POS_ORN, nb_deriv=1, T=200, dt=0.05, B=4096, seed=2, Qdiag=[P, P], solver="recursive", nb_iter=20),
+        "C4": dict(kind=capi.SYS_POS_ORN_TIME, nb_deriv=2, T=200, dt=None, B=4096, seed=3, Qdiag=[P + V + [.1], P + V + [.1]],
+                   ctimes=[2.5, 5.0], solver="recursive", nb_iter=20),
+        "C5": dict(kind=capi.SYS_POS_ORN, nb_deriv=1, T=400, dt=0.01, B=8192, seed=4, Qdiag=[P, P], solver="batch_cp", nb_iter=10,
+                   psi=dict(kind="unitstep", K=2)),
+    }
+    return dict(cfgs[name])
+
+
+def make_batch(ctx: capi.Context, cfg: dict, B: int | None = None, seed: int | None = None, limits: str = "inactive", chain=None):
+    """Returns (desc, inputs) where inputs = dict(q0, dq0, targets[list per keypoint], U0, [A, b, lambda0])."""
+    B = int(B if B is not None else cfg["B"])
+    seed = int(seed if seed is not None else cfg["seed"])
+    chain = chain or panda_chain()
+    dof = chain["dof"]
+    lo, up = chain["lower"], chain["upper"]
+    rng = np.random.default_rng(seed)
+    kind, nd, T = cfg["kind"], cfg["nb_deriv"], cfg["T"]
+    tm = 1 if kind == capi.SYS_POS_ORN_TIME else 0
+    nu = dof + tm
+    kp_t = [T // 2 - 1, T - 1]
+    if limits == "inactive":
+        qmax = np.full(dof, 10 * np.pi)
+        qmin = -qmax
+    else:
+        qmax, qmin = up.copy(), lo.copy()
+    nx = nd * dof + tm
+    smax, smin, w = np.zeros(nx), np.zeros(nx), np.zeros(nx, dtype=int)
+    smax[:dof], smin[:dof], w[:dof] = qmax, qmin, 1
+    if nd == 2:
+        smax[dof:2 * dof], smin[dof:2 * dof], w[dof:2 * dof] = 10.0, -10.0, 1
+    desc = capi.make_desc(kind=kind, nb_deriv=nd, horizon=T, dt=cfg["dt"], R_diag=[1e-5] * nu, chain=chain, kp_timesteps=kp_t,
+                          kp_Q=[np.diag(q) for q in cfg["Qdiag"]], limits=dict(state_max=smax, state_min=smin, limit_weight=w, penalty=1.0))
+    q0 = np.clip(Q0_TUT[None, :] + rng.uniform(-0.3, 0.3, (B, dof)), lo, up)
+    targets = []
+    for i in range(2):
+        qr = rng.uniform(lo, up, (B, dof))
+        pos, quat, _ = ctx.fk_batch(desc, qr)
+        cols = [pos, quat]
+        if nd == 2:
+            cols += [np.zeros((B, 3)), np.zeros((B, 4))]
+        if tm:
+            cols += [np.full((B, 1), cfg["ctimes"][i])]
+        targets.append(np.ascontiguousarray(np.hstack(cols)))
+    U0 = np.zeros((B, T - 1, nu))
+    if tm:
+        U0[:, :, -1] = 0.01
+    inp = dict(q0=q0, dq0=np.zeros((B, dof)), targets=targets, U0=U0, kp_t=kp_t, limits=dict(state_max=smax, state_min=smin, limit_weight=w))
+    if cfg.get("al"):
+        al = cfg["al"]
+        A = np.zeros((1, nx + nu))
+        A[0, al["row"]] = 1.0
+        inp.update(A=A, b=np.array([al["bound"]]), lambda0=np.full((B, T - 1, 1), al["bound"]))  # tutorial: init multipliers = b
+    return desc, inp
+
+
+def load_batch(ctx: capi.Context, desc, inp, B: int) -> capi.BatchProblem:
+    p = capi.BatchProblem(ctx, desc, B)
+    p.set_init_state(inp["q0"], inp["dq0"])
+    for k, t in enumerate(inp["targets"]):
+        p.set_keypoint_targets(k, t)
+    p.set_controls(inp["U0"])
+    if "A" in inp:
+        p.set_constraints(inp["A"], inp["b"], inp["lambda0"])
+    return p
+
+
+def run_solver(p: capi.BatchProblem, cfg: dict, nb_iter=None, early_stop=False, psi=None):
+    n = int(nb_iter if nb_iter is not None else cfg["nb_iter"])
+    if cfg["solver"] == "recursive":
+        p.solve_recursive(n, True, early_stop)
+    elif cfg["solver"] == "al":
+        al = cfg["al"]
+        p.solve_al(n, al["lag"], al["penalty"], al["scaling"], True, early_stop)
+    else:
+        p.solve_batch_cp(psi, n, early_stop)
+    return n

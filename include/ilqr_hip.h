@@ -1,0 +1,187 @@
+/*
+ * ilqr_hip.h -- C ABI of the MI355X-native batched iLQR hot path (libilqr_hip.so).
+ *
+ * The reference (idiap/ilqr_planner) has no FFI layer: its solvers call `sys::System` virtuals in-process
+ * and solve ONE problem per call.  This library is what a maintainer binds under the reference's solver
+ * classes to solve B independent instances of one System at once on an MI355X.  Each entry point cites the
+ * reference interface it replaces (paths relative to ilqr_planner/ilqr_planner in the reference tree).
+ *
+ * Conventions
+ *  - plain C, POD structs, raw pointers + sizes; no C++/torch types.
+ *  - every function returning int returns 0 on success, non-zero on error; the message is
+ *    ilqr_last_error(ctx).  The C++ host layer turns non-zero into std::runtime_error (the reference's only
+ *    error convention, e.g. src/sim/KDLRobot.cpp:49,95; src/system/System.cpp:366).
+ *  - host arrays are row-major, batch OUTERMOST ("natural" layout: instance b is what the reference would have
+ *    been given / returned for that instance): X[B][T][n_x], U[B][T-1][n_u], K[B][T-1][n_u][n_x] ...
+ *    The callee never keeps a host pointer after return.  Device layout is private.
+ *  - `*_dev` variants take/return DEVICE pointers in the same natural layout (for callers whose data already
+ *    lives in HBM, e.g. torch tensors); all work is enqueued on the context's stream.
+ *  - one context per host thread; calls on one context are serialised by the caller.
+ *  - all arithmetic is IEEE double, as in the reference (Eigen::MatrixXd everywhere).
+ */
+#ifndef ILQR_HIP_H
+#define ILQR_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ILQR_MAX_SEG 24
+#define ILQR_MAX_KP 8
+#define ILQR_MAX_NX 15
+#define ILQR_MAX_NU 8
+#define ILQR_MAX_NF 15
+#define ILQR_MAX_NQ 13
+
+/* system kinds: which sys::System subclass is being lowered */
+#define ILQR_SYS_POS_ORN 0      /* sys::PosOrnPlannerSys      (src/system/PosOrnPlannerSys.cpp) */
+#define ILQR_SYS_POS_ORN_TIME 1 /* sys::PosOrnTimePlannerSys  (src/system/PosOrnTimePlannerSys.cpp) */
+
+/* per-instance status word */
+#define ILQR_STATUS_OK 0
+#define ILQR_STATUS_NONFINITE 1   /* accepted cost is NaN/Inf (the reference prints -nan and carries on) */
+#define ILQR_STATUS_ALPHA_FLOOR 2 /* last line search bottomed out at alpha <= alpha_floor (accept-anyway rule) */
+
+typedef struct ilqr_ctx ilqr_ctx;
+typedef struct ilqr_problem ilqr_problem;
+
+/*
+ * Flat description of one sys::System + its sim::KDLRobot, shared by all B instances.
+ * Replaces what the solvers read through System virtuals:
+ *   chain            <- KDLRobot's KDL::Chain after TinyURDFParser + the "robot_custom_tip" segment
+ *                       (src/sim/KDLRobot.cpp:45-66): segment s is Trans(xyz) * R * Rot(axis, q[joint]) .
+ *   kind,nb_deriv,dt <- System subclass + localInit (src/system/PosOrnPlannerSys.cpp:54-78,
+ *                       src/system/PosOrnTimePlannerSys.cpp:50-83)
+ *   R_diag           <- System::R (src/system/System.cpp:41,73)
+ *   limits_*         <- state_max_/state_min_/joint_limits_weight_/penalty_ (src/system/System.cpp:38-61)
+ *   kp_*             <- Keypoint::getTimestep()/getPrecision() (include/ilqr_planner/system/Keypoint.h:23-35);
+ *                       timesteps must be unique and ascending (System.cpp:77-86 sorts them; a std::map keeps the
+ *                       last of duplicates).  Keypoint TARGETS are per instance: ilqr_problem_set_keypoint_targets.
+ *   reg,alpha_floor,stop_tol <- hard-coded constants of ILQRRecursive.cpp:89,155,174
+ */
+typedef struct {
+    int kind;      /* ILQR_SYS_* */
+    int nb_deriv;  /* 1 or 2 */
+    int dof;       /* moving joints of the chain (device path: 7) */
+    int horizon;   /* T */
+    double dt;     /* PosOrn only; time systems take dt = u_last^2 */
+    double R_diag[ILQR_MAX_NU];
+    int limits_set;
+    double penalty;
+    double state_max[ILQR_MAX_NX + 1], state_min[ILQR_MAX_NX + 1];
+    int limit_weight[ILQR_MAX_NX + 1];
+    int n_seg;
+    int seg_joint[ILQR_MAX_SEG];  /* -1 fixed, else joint index */
+    double seg_xyz[ILQR_MAX_SEG][3];
+    double seg_R[ILQR_MAX_SEG][9]; /* row-major */
+    double seg_axis[ILQR_MAX_SEG][3];
+    int n_kp;
+    int kp_timestep[ILQR_MAX_KP];
+    double kp_Q[ILQR_MAX_KP][ILQR_MAX_NQ * ILQR_MAX_NQ]; /* row-major n_Q x n_Q, leading dimension n_Q */
+    double reg;          /* 1e-6 */
+    double alpha_floor;  /* 1e-3 */
+    double stop_tol;     /* 1e-3 */
+} ilqr_problem_desc;
+
+/* dimensions derived from (kind, nb_deriv, dof): n_x, n_u, n_f (target space), n_Q (residual space) */
+typedef struct { int n_x, n_u, n_f, n_Q; } ilqr_dims;
+int ilqr_dims_of(const ilqr_problem_desc* desc, ilqr_dims* out);
+void ilqr_desc_defaults(ilqr_problem_desc* desc); /* zero + reg/alpha_floor/stop_tol defaults */
+
+/* ---- URDF -> chain (host only, no GPU needed) ------------------------------------------------------------- */
+/* What sim::KDLRobot's constructor gets from TinyURDFParser + KDL (src/sim/KDLRobot.cpp:45-66): fills
+ * desc->{dof, n_seg, seg_joint, seg_xyz, seg_R, seg_axis} with the joints from base_frame to tip_frame plus the user
+ * tool frame Frame(EulerZYX(tool_rpy[0], tool_rpy[1], tool_rpy[2]), tool_xyz) (NULL = identity) as a last fixed
+ * segment.  lower/upper (may be NULL) receive the URDF joint limits [dof].  Error text: ilqr_urdf_last_error()
+ * ("[KDLRobot] Unable to build kinematic chain from <base> to <tip>" as KDLRobot.cpp:49,56 throws). */
+int ilqr_chain_from_urdf(const char* urdf_text, const char* base_frame, const char* tip_frame, const double* tool_rpy,
+                         const double* tool_xyz, ilqr_problem_desc* desc, double* lower, double* upper);
+const char* ilqr_urdf_last_error(void);
+
+/* ---- context: device + stream + error text -------------------------------------------------------------- */
+int ilqr_ctx_create(int device_id, ilqr_ctx** out);
+void ilqr_ctx_destroy(ilqr_ctx* ctx);
+const char* ilqr_last_error(const ilqr_ctx* ctx);
+/* run everything on the caller's hipStream_t (e.g. torch's current stream); NULL = the context's own stream */
+int ilqr_ctx_set_stream(ilqr_ctx* ctx, void* hip_stream);
+int ilqr_ctx_synchronize(ilqr_ctx* ctx);
+const char* ilqr_version(void);
+
+/* ---- a batch of B instances of one System ---------------------------------------------------------------- */
+int ilqr_problem_create(ilqr_ctx* ctx, const ilqr_problem_desc* desc, int batch, ilqr_problem** out);
+void ilqr_problem_destroy(ilqr_problem* p);
+
+/* q0_/dq0_ captured by localInit (PosOrnPlannerSys.cpp:57-58): q0[B][dof], dq0[B][dof] (NULL = zeros) */
+int ilqr_problem_set_init_state(ilqr_problem* p, const double* q0, const double* dq0);
+/* Keypoint target in f(x) layout [p(3), quat wxyz(4) (, dp(3), dquat(4)) (, t)] : target[B][n_f]
+ * (PosOrnKeypoint ctor args, include/ilqr_planner/system/PosOrnKeypoint.h:18-33; SpacetimeKeypoint.h:17-33) */
+int ilqr_problem_set_keypoint_targets(ilqr_problem* p, int kp_index, const double* target);
+/* U0 of ILQRRecursive::solve / AL_ILQR::solve (include/ilqr_planner/solver/ILQRRecursive.h:36): U0[B][T-1][n_u].
+ * Kept on the device so a solve can be repeated from the same start (ilqr_solve_* always restart from it). */
+int ilqr_problem_set_controls(ilqr_problem* p, const double* U0);
+/* solver::Constraint list + initLambda of AL_ILQR's ctor (include/ilqr_planner/solver/AL-ILQR.h:20-36):
+ * A is m x (n_x+n_u), b is m; per_step=0: one (A,b) for every k, else A[T-1][m][n_x+n_u], b[T-1][m];
+ * shared by all instances.  lambda0[B][T-1][m] (NULL = zeros). */
+int ilqr_problem_set_constraints(ilqr_problem* p, int m, int per_step, const double* A, const double* b, const double* lambda0);
+/* put the multipliers back to the lambda0 given to ilqr_problem_set_constraints (= constructing a fresh AL_ILQR) */
+int ilqr_problem_reset_multipliers(ilqr_problem* p);
+/* device-pointer variants (same layouts, memory already in HBM) */
+int ilqr_problem_set_init_state_dev(ilqr_problem* p, const double* q0, const double* dq0);
+int ilqr_problem_set_keypoint_targets_dev(ilqr_problem* p, int kp_index, const double* target);
+int ilqr_problem_set_controls_dev(ilqr_problem* p, const double* U0);
+
+/* ---- solvers ----------------------------------------------------------------------------------------------- */
+/* ILQRRecursive::solve(U0, nb_iter, line_search, early_stop, cb)  (src/solver/ILQRRecursive.cpp:21-181),
+ * for all B instances; asynchronous on the context's stream. */
+int ilqr_solve_recursive(ilqr_problem* p, int nb_iter, int line_search, int early_stop);
+/* AL_ILQR::solve(U0, nb_iter, lag_update_step, penalty, scaling_factor, line_search, early_stop, cb)
+ * (src/solver/AL-ILQR.cpp:50-232); multipliers persist in the problem across calls like the reference's
+ * `multipliers` member unless re-set with ilqr_problem_set_constraints. */
+int ilqr_solve_al(ilqr_problem* p, int nb_iter, int lag_update_step, double penalty, double scaling_factor,
+                  int line_search, int early_stop);
+/* BatchILQRCP::solve(nb_iter, u0, early_stop, cb) (src/solver/BatchILQRCP.cpp:109-175) with the shared basis
+ * PSI ((T-1) n_u x Kw, row-major); u0 = the controls set with ilqr_problem_set_controls. */
+int ilqr_solve_batch_cp(ilqr_problem* p, const double* psi, int Kw, int nb_iter, int early_stop);
+
+/* ---- results (host, natural layout); each synchronises the stream ------------------------------------------ */
+int ilqr_problem_get_X(ilqr_problem* p, double* X);       /* [B][T][n_x]     ILQRRecursive tuple<0> */
+int ilqr_problem_get_fX(ilqr_problem* p, double* fX);     /* [B][T][n_f]     tuple<1> (one batched FK pass) */
+int ilqr_problem_get_U(ilqr_problem* p, double* U);       /* [B][T-1][n_u]   tuple<2> */
+int ilqr_problem_get_K(ilqr_problem* p, double* K);       /* [B][T-1][n_u][n_x] tuple<3> */
+int ilqr_problem_get_d(ilqr_problem* p, double* d);       /* [B][T-1][n_u]   tuple<4> (scaled by accepted alpha) */
+int ilqr_problem_get_cost(ilqr_problem* p, double* cost); /* [B]             tuple<5> */
+int ilqr_problem_get_alpha(ilqr_problem* p, double* alpha); /* [B] last accepted alpha */
+int ilqr_problem_get_iters(ilqr_problem* p, int* iters);  /* [B] iterations run (early stop) */
+int ilqr_problem_get_status(ilqr_problem* p, int* status);/* [B] ILQR_STATUS_* */
+int ilqr_problem_get_lambda(ilqr_problem* p, double* lambda); /* [B][T-1][m] */
+/* per-iteration stream the reference prints through CallBackMessage ("Iteration i, Cost: c, alpha= a",
+ * ILQRRecursive.cpp:167-172): cost_trace/alpha_trace[B][nb_iter] of the last solve (NaN after an early stop) */
+int ilqr_problem_get_trace(ilqr_problem* p, double* cost_trace, double* alpha_trace, int nb_iter);
+/* device-pointer variants */
+int ilqr_problem_get_X_dev(ilqr_problem* p, double* X);
+int ilqr_problem_get_U_dev(ilqr_problem* p, double* U);
+int ilqr_problem_get_cost_dev(ilqr_problem* p, double* cost);
+
+/* ---- stand-alone batched kinematics: KDLRobot::updateKinematics for n configurations ---------------------- */
+/* (src/sim/KDLRobot.cpp:83-115): q[n][dof] (dq[n][dof] or NULL) -> pos[n][3], quat[n][4] (w,x,y,z), jac[n][6][dof];
+ * any output may be NULL.  Host pointers. */
+int ilqr_fk_batch(ilqr_ctx* ctx, const ilqr_problem_desc* desc, int n, const double* q, double* pos, double* quat, double* jac);
+
+/* ---- instrumentation ----------------------------------------------------------------------------------------- */
+/* When enabled, every kernel launch is bracketed by hipEvents on the launch stream; totals are read back with
+ * ilqr_profile_get (index: ILQR_PROF_*).  Used by bench.py for the roofline figures. */
+#define ILQR_PROF_ROLLOUT 0
+#define ILQR_PROF_BACKWARD 1
+#define ILQR_PROF_FORWARD 2
+#define ILQR_PROF_OTHER 3
+#define ILQR_PROF_COUNT 4
+int ilqr_profile_enable(ilqr_ctx* ctx, int on);
+int ilqr_profile_reset(ilqr_ctx* ctx);
+int ilqr_profile_get(ilqr_ctx* ctx, int which, double* total_ms, int* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -136,3 +136,6 @@ for j in root.findall("joint"):
 lines.append("</robot>")
 open(os.path.join(OUT, "panda_chain.urdf"), "w").write("\n".join(lines) + "\n")
 print("wrote traces.json (%d cases) and panda_chain.urdf" % len(cases))
+# the same skeleton ships with the package so bench.py / smoke() need nothing outside the repo
+import shutil
+shutil.copyfile(os.path.join(OUT, "panda_chain.urdf"), os.path.join(os.path.dirname(os.path.dirname(OUT)), "ilqr_planner_amd", "data", "panda_chain.urdf"))

@@ -71,3 +71,41 @@ def assert_trace(got_cost, got_alpha, trace):
             # the printed value has 6 significant digits: allow half a unit in the last place (+ slack for rounding ties)
             ulp6 = 10.0 ** (np.floor(np.log10(abs(c_ref))) - 5)
             assert abs(c - c_ref) <= 0.51 * ulp6, f"iteration {i+1}: cost {c!r} vs {c_ref!r}"
+
+
+# ----------------------------------------------------------------------------- synthetic batches (ilqr_planner_amd.workloads) -> oracle
+
+
+def oracle_system_of_instance(cfg, inp, i, segs=None):
+    """Oracle System for instance i of a batch made by ilqr_planner_amd.workloads.make_batch."""
+    segs = segs or panda_segs()
+    nd = cfg["nb_deriv"]
+    tm = cfg["kind"] == 1
+    kps = []
+    for k, ts in enumerate(inp["kp_t"]):
+        tg = inp["targets"][k][i]
+        d = dict(timestep=ts, pos=tg[0:3], orn=tg[3:7], Q=np.diag(cfg["Qdiag"][k]))
+        if nd == 2:
+            d.update(dpos=tg[7:10], dorn=tg[10:14])
+        if tm:
+            d["ctime"] = tg[-1]
+        kps.append(d)
+    dof = 7
+    lim = inp["limits"]
+    qMax, qMin = lim["state_max"][:dof], lim["state_min"][:dof]
+    dqMax = lim["state_max"][dof:2 * dof] if nd == 2 else None
+    dqMin = lim["state_min"][dof:2 * dof] if nd == 2 else None
+    nu = dof + (1 if tm else 0)
+    return orc.make_system(segs, orc.SYS_POS_ORN_TIME if tm else orc.SYS_POS_ORN, nd, cfg["T"], cfg["dt"], [1e-5] * nu, kps,
+                           inp["q0"][i], inp["dq0"][i], qMax, qMin, dqMax, dqMin)
+
+
+def oracle_solve_instance(cfg, inp, i, nb_iter, early_stop, segs=None):
+    s = oracle_system_of_instance(cfg, inp, i, segs)
+    U0 = inp["U0"][i].reshape(-1)
+    if cfg["solver"] == "recursive":
+        return orc.solve_recursive(s, U0, nb_iter, True, early_stop)
+    if cfg["solver"] == "al":
+        al = cfg["al"]
+        return orc.solve_al(s, inp["A"], inp["b"], inp["lambda0"][i], U0, nb_iter, al["lag"], al["penalty"], al["scaling"], True, early_stop)
+    raise KeyError(cfg["solver"])
