@@ -95,7 +95,9 @@ def main():
     B = int(args.batch or cfg["B"])
     nb_iter = int(args.iters or cfg["nb_iter"])
     ctx = capi.Context(local_rank)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # so torch's barrier/synchronize bracket our launches
+    stream = torch.cuda.Stream()  # a real (non-null) stream shared by the library's launches and torch's collectives
+    torch.cuda.set_stream(stream)
+    ctx.set_stream(stream.cuda_stream)
     desc, inp = workloads.make_batch(ctx, cfg, B=B, seed=cfg["seed"] + 1000 * rank)
     p = workloads.load_batch(ctx, desc, inp, B)  # inputs resident in HBM from here on
     psi = None
