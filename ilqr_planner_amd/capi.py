@@ -187,8 +187,11 @@ def make_desc(*, kind, nb_deriv, horizon, dt, R_diag, chain, kp_timesteps, kp_Q,
 
 class Context:
     def __init__(self, device_id: int = 0):
+        import weakref
+
         self.L = load()
         self.h = C.c_void_p()
+        self._problems = weakref.WeakSet()
         rc = self.L.ilqr_ctx_create(device_id, C.byref(self.h))
         if rc:
             raise RuntimeError(f"ilqr_ctx_create failed (code {rc}): no usable HIP device {device_id}; there is no CPU fallback")
@@ -223,6 +226,8 @@ class Context:
 
     def close(self):
         if self.h:
+            for p in list(self._problems):
+                p.close()
             self.L.ilqr_ctx_destroy(self.h)
             self.h = C.c_void_p()
 
@@ -243,6 +248,7 @@ class BatchProblem:
         self.T = desc.horizon
         self.h = C.c_void_p()
         ctx.check(self.L.ilqr_problem_create(ctx.h, C.byref(desc), self.B, C.byref(self.h)))
+        ctx._problems.add(self)
         self.m = 0
 
     # ---- inputs (host arrays)
@@ -347,7 +353,8 @@ class BatchProblem:
 
     def close(self):
         if self.h:
-            self.L.ilqr_problem_destroy(self.h)
+            if self.ctx.h:  # a destroyed context has already destroyed its problems
+                self.L.ilqr_problem_destroy(self.h)
             self.h = C.c_void_p()
 
     def __del__(self):

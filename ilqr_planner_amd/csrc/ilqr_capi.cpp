@@ -31,6 +31,7 @@ struct ilqr_ctx {
     struct Pending { hipEvent_t a, b; int which; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> pool;
+    std::vector<ilqr_problem*> problems;  // live problems of this context (destroyed with it)
 };
 
 struct ilqr_problem {
@@ -108,6 +109,7 @@ extern "C" int ilqr_ctx_create(int device_id, ilqr_ctx** out) {
 extern "C" void ilqr_ctx_destroy(ilqr_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    while (!c->problems.empty()) ilqr_problem_destroy(c->problems.back());  // handles held by the caller become invalid
     (void)hipStreamSynchronize(c->stream);
     for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : c->pool) (void)hipEventDestroy(e);
@@ -278,6 +280,7 @@ extern "C" int ilqr_problem_create(ilqr_ctx* c, const ilqr_problem_desc* d, int 
     HIPCHK(c, hipSetDevice(c->device));
     auto* p = new ilqr_problem();
     p->ctx = c;
+    c->problems.push_back(p);
     p->desc = *d;
     p->B = batch;
     p->Bp = (batch + 63) / 64 * 64;
@@ -315,6 +318,8 @@ extern "C" int ilqr_problem_create(ilqr_ctx* c, const ilqr_problem_desc* d, int 
 
 extern "C" void ilqr_problem_destroy(ilqr_problem* p) {
     if (!p) return;
+    for (auto it = p->ctx->problems.begin(); it != p->ctx->problems.end(); ++it)
+        if (*it == p) { p->ctx->problems.erase(it); break; }
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
     for (void* q : p->allocs) (void)hipFree(q);
