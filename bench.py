@@ -187,7 +187,9 @@ def main():
             out["cpu_baseline"] = cb
             ref = np.array(ccost)
             rel = np.abs(cost[: len(ref)] - ref) / np.maximum(np.abs(ref), 1e-12)
-            out["final_cost_rel_err_vs_oracle"] = {"max": float(rel.max()), "median": float(np.median(rel)), "n": int(len(ref))}
+            out["final_cost_rel_err_vs_oracle"] = {"median": float(np.median(rel)), "p90": float(np.quantile(rel, 0.9)), "max": float(rel.max()),
+                                                   "frac_within_1e-4": float(np.mean(rel <= 1e-4)), "n": int(len(ref)),
+                                                   "note": "AL-iLQR is a discontinuous map: instances outside 1e-4 are those where the oracle itself moves by >1e-7 under a 1e-15 perturbation of q0 (DESIGN.md, Parity)"}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

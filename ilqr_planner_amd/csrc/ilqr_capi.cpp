@@ -280,7 +280,6 @@ extern "C" int ilqr_problem_create(ilqr_ctx* c, const ilqr_problem_desc* d, int 
     HIPCHK(c, hipSetDevice(c->device));
     auto* p = new ilqr_problem();
     p->ctx = c;
-    c->problems.push_back(p);
     p->desc = *d;
     p->B = batch;
     p->Bp = (batch + 63) / 64 * 64;
@@ -312,6 +311,7 @@ extern "C" int ilqr_problem_create(ilqr_ctx* c, const ilqr_problem_desc* d, int 
         ilqr_problem_destroy(p);
         return fail(c, "descriptor upload failed");
     }
+    c->problems.push_back(p);
     *out = p;
     return 0;
 }

@@ -109,3 +109,15 @@ def oracle_solve_instance(cfg, inp, i, nb_iter, early_stop, segs=None):
         al = cfg["al"]
         return orc.solve_al(s, inp["A"], inp["b"], inp["lambda0"][i], U0, nb_iter, al["lag"], al["penalty"], al["scaling"], True, early_stop)
     raise KeyError(cfg["solver"])
+
+
+class OracleFK:
+    """Stand-in for capi.Context in CPU-only experiments/tests: workloads.make_batch only needs fk_batch()."""
+
+    def fk_batch(self, desc, q):
+        ch = orc.make_chain(panda_segs())
+        q = np.asarray(q, float)
+        pos, quat = np.zeros((len(q), 3)), np.zeros((len(q), 4))
+        for i in range(len(q)):
+            pos[i], quat[i], *_ = orc.fk(ch, q[i])
+        return pos, quat, None
