@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output directories (kernel-trace --stats, and separate --pmc passes) into one text summary.
+usage: summarize_profile.py OUT.txt STATS_DIR [PMC_DIR ...]"""
+import collections
+import csv
+import glob
+import os
+import sys
+
+out, stats_dir, pmc_dirs = sys.argv[1], sys.argv[2], sys.argv[3:]
+lines = []
+for f in glob.glob(os.path.join(stats_dir, "**", "*kernel_stats.csv"), recursive=True):
+    lines.append(f"# rocprofv3 --kernel-trace --stats : {os.path.relpath(f)}")
+    lines.append(f"{'kernel':<70} {'calls':>6} {'avg_us':>12} {'total_ms':>10} {'pct':>6}")
+    for r in csv.DictReader(open(f)):
+        lines.append(f"{r['Name'][:70]:<70} {r['Calls']:>6} {float(r['AverageNs'])/1e3:>12.1f} {float(r['TotalDurationNs'])/1e6:>10.2f} {float(r['Percentage']):>6.2f}")
+for d in pmc_dirs:
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        agg = collections.defaultdict(lambda: [0, 0.0])
+        meta = {}
+        for r in csv.DictReader(open(f)):
+            k = (r["Kernel_Name"][:70], r["Counter_Name"])
+            agg[k][0] += 1
+            agg[k][1] += float(r["Counter_Value"])
+            meta[r["Kernel_Name"][:70]] = (r["VGPR_Count"], r["Accum_VGPR_Count"], r["SGPR_Count"], r["Scratch_Size"], r["LDS_Block_Size"])
+        lines.append(f"# rocprofv3 --pmc : {os.path.relpath(f)}  (per-dispatch average; FETCH_SIZE/WRITE_SIZE in KiB; on gfx950 FETCH_SIZE counts half of a coalesced stream)")
+        for (k, c), (n, s) in sorted(agg.items()):
+            v, a, sg, sc, lds = meta[k]
+            lines.append(f"{k:<70} {c:<12} n={n:<4} avg={s/n:>14.1f}   vgpr={v} agpr={a} sgpr={sg} scratch={sc} lds={lds}")
+open(out, "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
