@@ -138,7 +138,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    prof = {n: ctx.profile_get(w) for n, w in (("rollout", capi.PROF_ROLLOUT), ("backward", capi.PROF_BACKWARD), ("forward", capi.PROF_FORWARD))}
+    prof = {n: ctx.profile_get(w) for n, w in (("rollout", capi.PROF_ROLLOUT), ("backward", capi.PROF_BACKWARD), ("forward", capi.PROF_FORWARD),
+                                               ("apply", capi.PROF_APPLY))}
     cost = cost_dev.cpu().numpy()
     status = p.status()
     at = p.trace(nb_iter)[1] if cfg["solver"] != "batch_cp" else None
@@ -146,10 +147,15 @@ def main():
     if rank == 0:
         nx, nu, m = p.dims.n_x, p.dims.n_u, p.m
         bwd_bytes, fwd_bytes = algorithmic_bytes(nx, nu, m, cfg["T"], B)
-        # forward launches run a data-dependent number of line-search trials: mean trials from the alpha trace
+        # mean number of step sizes the reference's do/while would have tried, and the share of instance-iterations whose
+        # winner was not alpha = 1 (those are re-rolled by the second forward pass)
         trials = float(np.mean(1 + np.round(-np.log2(at)))) if at is not None else 1.0
+        frac_apply = float(np.mean(at < 1.0)) if at is not None else 0.0
+        v1 = os.environ.get("ILQR_HIP_PATH") == "v1"
         kern = {}
-        for name, byts in (("backward", bwd_bytes), ("forward", fwd_bytes * trials)):
+        # v2: the speculative pass reads K,d,x,u once and writes the alpha=1 trajectory once, whatever the trial count;
+        # v1: one full read+write per sequential trial
+        for name, byts in (("backward", bwd_bytes), ("forward", fwd_bytes * (trials if v1 else 1.0)), ("apply", fwd_bytes * frac_apply)):
             ms, n = prof[name]
             if n:
                 avg = ms / n

@@ -11,6 +11,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -26,8 +27,8 @@ struct ilqr_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     bool profile = false;
-    double prof_ms[ILQR_PROF_COUNT] = {0, 0, 0, 0};
-    int prof_n[ILQR_PROF_COUNT] = {0, 0, 0, 0};
+    double prof_ms[ILQR_PROF_COUNT] = {0, 0, 0, 0, 0};
+    int prof_n[ILQR_PROF_COUNT] = {0, 0, 0, 0, 0};
     struct Pending { hipEvent_t a, b; int which; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> pool;
@@ -45,6 +46,7 @@ struct ilqr_problem {
     std::vector<void*> allocs;
     double *conA = nullptr, *conb = nullptr;  // device copies of the shared constraint rows
     double* lambda0 = nullptr;                // initial multipliers, kept for ilqr_problem_reset_multipliers
+    bool con_state_only = false;              // no constraint row touches the controls (enables the closed-form sweep)
     int trace_iters = 0;
     double* staging = nullptr;  // device staging for host<->device natural-layout transfers
     size_t staging_elems = 0;
@@ -304,6 +306,7 @@ extern "C" int ilqr_problem_create(ilqr_ctx* c, const ilqr_problem_desc* d, int 
     rc |= dalloc(p, &b.active, Bp);
     rc |= dalloc(p, &b.iters, Bp);
     rc |= dalloc(p, &b.status, Bp);
+    rc |= dalloc(p, &b.pend, Bp);
     if (rc) { ilqr_problem_destroy(p); return 1; }
     b.U0 = U0; b.q0 = q0; b.dq0 = dq0; b.kp_tg = tg; b.desc = p->ddesc;
     if (hipMemcpyAsync(p->ddesc, &p->hdesc, sizeof(DevDesc), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
@@ -395,6 +398,10 @@ extern "C" int ilqr_problem_set_constraints(ilqr_problem* p, int m, int per_step
     HIPCHK(c, hipMemcpyAsync(p->conb, b, nk * m * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     p->bufs.m = m; p->bufs.per_step = per_step; p->bufs.conA = p->conA; p->bufs.conb = p->conb;
+    p->con_state_only = true;
+    for (size_t k = 0; k < nk * m; k++)
+        for (int j = p->dims.n_x; j < ns; j++)
+            if (A[k * ns + j] != 0.0) p->con_state_only = false;
     if (lambda0) {
         if (upload(p, lambda0, false, p->bufs.lambda, (T - 1) * m)) return 1;
     } else {
@@ -429,6 +436,17 @@ static int ensure_trace(ilqr_problem* p, int nb_iter) {
     return 0;
 }
 
+// Which kernels run an iteration.  v2 (default): closed-form single-integrator sweep where it applies, alpha-parallel
+// line search everywhere.  ILQR_HIP_PATH=v1 forces the generic lane-per-instance kernels (used by the parity tests to
+// cross-check the two paths); ILQR_HIP_PATH=v2fwd keeps the generic sweep with the alpha-parallel forward.
+static int path_choice() {
+    const char* e = std::getenv("ILQR_HIP_PATH");
+    if (!e) return 2;
+    if (!std::strcmp(e, "v1")) return 1;
+    if (!std::strcmp(e, "v2fwd")) return 3;
+    return 2;
+}
+
 static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double penalty, double scaling, int line_search, int early_stop) {
     if (!p) return 1;
     ilqr_ctx* c = p->ctx;
@@ -438,27 +456,48 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
     HIPCHK(c, hipSetDevice(c->device));
     if (ensure_trace(p, nb_iter)) return 1;
     p->last_nb_iter = nb_iter;
+    const int kind = p->desc.kind, nd = p->desc.nb_deriv;
+    // number of step sizes the do/while of ILQRRecursive.cpp:101-155 can reach: 1, 1/2, ... until alpha <= alpha_floor
+    int n_alpha = 1;
+    if (line_search) { double al_ = 1.0; while (al_ > p->desc.alpha_floor && n_alpha < 64) { al_ *= 0.5; n_alpha++; } }
+    const int path = path_choice();
+    const bool fwd_tile = (path != 1) && n_alpha <= 16;
+    const bool bwd_si = (path == 2) && kind == ILQR_SYS_POS_ORN && nd == 1 && (!al || p->con_state_only);
     FwdArgs f;
     std::memset(&f, 0, sizeof(f));
-    f.line_search = line_search; f.early_stop = early_stop; f.nb_iter = nb_iter; f.penalty_roll = penalty;
+    f.line_search = line_search; f.early_stop = early_stop; f.nb_iter = nb_iter; f.penalty_roll = penalty; f.n_alpha = n_alpha;
     {
         ProfScope ps(c, ILQR_PROF_ROLLOUT);
-        launch_solver(p->desc.kind, p->desc.nb_deriv, KER_INIT, al, p->bufs, p->B, c->stream, f);
+        launch_solver(kind, nd, KER_INIT, al, p->bufs, p->B, c->stream, f);
     }
     HIPCHK(c, hipGetLastError());
     for (int it = 0; it < nb_iter; it++) {
         {
             ProfScope ps(c, ILQR_PROF_BACKWARD);
-            launch_solver(p->desc.kind, p->desc.nb_deriv, KER_BACKWARD, al, p->bufs, p->B, c->stream, f);
+            if (bwd_si) launch_solver_v2(kind, nd, KER_BACKWARD_SI, al, p->bufs, p->B, p->T, c->stream, f);
+            else launch_solver(kind, nd, KER_BACKWARD, al, p->bufs, p->B, c->stream, f);
         }
         f.it = it;
         f.penalty_roll = penalty;  // I_k is stored pre-multiplied by the penalty current at rollout time (AL-ILQR.cpp:190)
         f.do_update = al && ((it + 1) % lag == 0);
         if (f.do_update) penalty *= scaling;  // multipliers use the UPDATED penalty (AL-ILQR.cpp:203-205)
         f.penalty_update = penalty;
-        {
+        if (fwd_tile) {
+            {
+                ProfScope ps(c, ILQR_PROF_FORWARD);
+                launch_solver_v2(kind, nd, KER_FWD_SPEC, al, p->bufs, p->B, p->T, c->stream, f);
+            }
+            if (line_search) {
+                ProfScope ps(c, ILQR_PROF_APPLY);
+                launch_solver_v2(kind, nd, KER_FWD_APPLY, al, p->bufs, p->B, p->T, c->stream, f);
+            }
+            if (f.do_update) {
+                ProfScope ps(c, ILQR_PROF_OTHER);
+                launch_solver_v2(kind, nd, KER_AL_UPDATE, al, p->bufs, p->B, p->T, c->stream, f);
+            }
+        } else {
             ProfScope ps(c, ILQR_PROF_FORWARD);
-            launch_solver(p->desc.kind, p->desc.nb_deriv, KER_FORWARD, al, p->bufs, p->B, c->stream, f);
+            launch_solver(kind, nd, KER_FORWARD, al, p->bufs, p->B, c->stream, f);
         }
         HIPCHK(c, hipGetLastError());
     }

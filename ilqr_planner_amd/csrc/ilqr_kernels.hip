@@ -11,170 +11,9 @@
 //   forward pass + line search src/solver/ILQRRecursive.cpp:101-176 (AL: src/solver/AL-ILQR.cpp:149-227)
 // A_k, B_k are never stored: they are rebuilt from (x_k, u_k) exactly as forwardPass builds them.
 #include "ilqr_kernels.hpp"
+#include "ilqr_step.hpp"
 
 namespace ilqr {
-
-#define UNR _Pragma("unroll")
-#define AT(buf, row, b) (buf)[(size_t)(row) * (size_t)Bp + (size_t)(b)]
-
-// ------------------------------------------------------------------------------------------------ helpers
-
-template <class S>
-ILQR_DEV void load_vec(const double* buf, int row0, int n, int Bp, int b, double* out) {
-    for (int i = 0; i < n; i++) out[i] = AT(buf, row0 + i, b);
-}
-
-// AL_ILQR::constraints (AL-ILQR.cpp:21-44): g = A [x;u] - b ; I = 0 iff (g<0 && lambda==0) ; stored as penalty*I
-template <class S>
-ILQR_DEV double con_g(const Bufs& a, int k, int r, const double* x, const double* u) {
-    const int ns = S::NX + S::NU;
-    const double* Ar = a.conA + ((size_t)(a.per_step ? k : 0) * a.m + r) * ns;
-    double g = 0;
-    UNR for (int i = 0; i < S::NX; i++) g += Ar[i] * x[i];
-    UNR for (int i = 0; i < S::NU; i++) g += Ar[S::NX + i] * u[i];
-    return g - a.conb[(size_t)(a.per_step ? k : 0) * a.m + r];
-}
-
-// lx, lxx of a stage (System::cost_x / cost_xx, System.cpp:248-308).  P <- lxx, p <- lx.
-template <class S>
-ILQR_DEV void stage_derivs(const DevDesc& d, const Bufs& a, int b, const double* x, int kpi, double (*lxx)[S::NX], double* lx) {
-    constexpr int NX = S::NX, NQ = S::NQ, NF = S::NF;
-    const int Bp = d.Bp;
-    UNR for (int i = 0; i < NX; i++) {
-        lx[i] = 0;
-        UNR for (int j = 0; j < NX; j++) lxx[i][j] = 0;
-    }
-    if (kpi >= 0) {
-        double fxv[NF], J[6][DOF], e[NQ], tg[NF], Qe[NQ];
-        fx_of<S, true>(d, x, fxv, J);
-        UNR for (int i = 0; i < NF; i++) tg[i] = AT(a.kp_tg, kpi * NF + i, b);
-        kp_diff<S>(tg, fxv, e);
-        const double* Q = d.kp_Q[kpi];
-        UNR for (int i = 0; i < NQ; i++) {
-            double s = 0;
-            UNR for (int j = 0; j < NQ; j++) s += Q[i * NQ + j] * e[j];
-            Qe[i] = s;
-        }
-        // Jf (NQ x NX) = blkdiag(J, J) bordered by 1 for the time state; lx = -Jf^T Q e ; lxx = Jf^T Q Jf
-        UNR for (int blk = 0; blk < S::ND; blk++) {
-            UNR for (int c = 0; c < DOF; c++) {
-                double s = 0;
-                UNR for (int r = 0; r < 6; r++) s += J[r][c] * Qe[6 * blk + r];
-                lx[DOF * blk + c] += -1 * s;
-            }
-        }
-        if (S::TM) lx[NX - 1] += -1 * Qe[NQ - 1];
-        // JtQ[c][r'] for c in block blk: sum_r J[r][c%7] Q[6 blk + r][r']
-        UNR for (int blk = 0; blk < S::ND; blk++) {
-            UNR for (int c = 0; c < DOF; c++) {
-                double jq[NQ];
-                UNR for (int rp = 0; rp < NQ; rp++) {
-                    double s = 0;
-                    UNR for (int r = 0; r < 6; r++) s += J[r][c] * Q[(6 * blk + r) * NQ + rp];
-                    jq[rp] = s;
-                }
-                UNR for (int blk2 = 0; blk2 < S::ND; blk2++) {
-                    UNR for (int c2 = 0; c2 < DOF; c2++) {
-                        double s = 0;
-                        UNR for (int r = 0; r < 6; r++) s += jq[6 * blk2 + r] * J[r][c2];
-                        lxx[DOF * blk + c][DOF * blk2 + c2] += s;
-                    }
-                }
-                if (S::TM) lxx[DOF * blk + c][NX - 1] += jq[NQ - 1];
-            }
-        }
-        if (S::TM) {
-            UNR for (int blk2 = 0; blk2 < S::ND; blk2++) {
-                UNR for (int c2 = 0; c2 < DOF; c2++) {
-                    double s = 0;
-                    UNR for (int r = 0; r < 6; r++) s += Q[(NQ - 1) * NQ + 6 * blk2 + r] * J[r][c2];
-                    lxx[NX - 1][DOF * blk2 + c2] += s;
-                }
-            }
-            lxx[NX - 1][NX - 1] += Q[(NQ - 1) * NQ + NQ - 1];
-        }
-    }
-    if (d.limits_set) {
-        UNR for (int i = 0; i < NX; i++) {
-            if (d.lw[i] != 0) {
-                double qv = 0, L = 0;
-                if (x[i] > d.smax[i]) { qv = d.smax[i] - x[i]; L = d.penalty; }
-                else if (x[i] < d.smin[i]) { qv = d.smin[i] - x[i]; L = d.penalty; }
-                lx[i] += -L * qv;
-                lxx[i][i] += L * L;
-            }
-        }
-    }
-}
-
-// Eigen MatrixXd::inverse() (PartialPivLU + solve against identity), fully unrolled, no dynamic indexing.
-template <int N>
-ILQR_DEV void inverse_lu(double (*M)[N], double (*Inv)[N]) {
-    int piv[N];
-    UNR for (int i = 0; i < N; i++) piv[i] = i;
-    UNR for (int k = 0; k < N; k++) {
-        // pivot search: first row with the largest |M[r][k]|, r >= k
-        double best = fabs(M[k][k]);
-        int r = k;
-        UNR for (int i = k + 1; i < N; i++) {
-            double v = fabs(M[i][k]);
-            if (v > best) { best = v; r = i; }
-        }
-        UNR for (int i = k + 1; i < N; i++) {
-            bool sw = (r == i);
-            UNR for (int j = 0; j < N; j++) {
-                double t0 = M[k][j], t1 = M[i][j];
-                M[k][j] = sw ? t1 : t0;
-                M[i][j] = sw ? t0 : t1;
-            }
-            int p0 = piv[k], p1 = piv[i];
-            piv[k] = sw ? p1 : p0;
-            piv[i] = sw ? p0 : p1;
-        }
-        double pv = M[k][k];
-        UNR for (int i = k + 1; i < N; i++) {
-            M[i][k] /= pv;
-            double f = M[i][k];
-            UNR for (int j = k + 1; j < N; j++) M[i][j] -= f * M[k][j];
-        }
-    }
-    UNR for (int c = 0; c < N; c++) {
-        UNR for (int i = 0; i < N; i++) {
-            double s = (piv[i] == c) ? 1.0 : 0.0;
-            UNR for (int j = 0; j < i; j++) s -= M[i][j] * Inv[j][c];
-            Inv[i][c] = s;
-        }
-        UNR for (int i = N - 1; i >= 0; i--) {
-            double s = Inv[i][c];
-            UNR for (int j = i + 1; j < N; j++) s -= M[i][j] * Inv[j][c];
-            Inv[i][c] = s / M[i][i];
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------ rollout pieces
-
-// stage cost l(x,u,k) (System::cost): task part only at keypoint steps, limits always
-template <class S>
-ILQR_DEV double stage_cost(const DevDesc& d, const Bufs& a, int b, int kpi, const double* x, const double* u) {
-    const int Bp = d.Bp;
-    double c = 0;
-    if (kpi >= 0) {
-        double tg[S::NF];
-        UNR for (int i = 0; i < S::NF; i++) tg[i] = AT(a.kp_tg, kpi * S::NF + i, b);
-        c += kp_cost<S>(d, kpi, tg, x, u);
-    }
-    if (d.limits_set) c += limit_cost<S>(d, x);
-    return c;
-}
-
-template <class S>
-ILQR_DEV void init_state(const DevDesc& d, const Bufs& a, int b, double* x) {
-    const int Bp = d.Bp;
-    UNR for (int i = 0; i < DOF; i++) x[i] = AT(a.q0, i, b);
-    if (S::ND == 2) { UNR for (int i = 0; i < DOF; i++) x[DOF + i] = AT(a.dq0, i, b); }
-    if (S::TM) x[S::NX - 1] = 0;
-}
 
 // ------------------------------------------------------------------------------------------------ kernels
 
@@ -220,6 +59,7 @@ __global__ __launch_bounds__(64) void k_init_rollout(Bufs a, double penalty) {
     a.cur[b] = 0;
     a.active[b] = 1;
     a.iters[b] = 0;
+    a.pend[b] = 0;
     a.status[b] = isfinite(cost) ? 0 : 1;
 }
 

@@ -23,6 +23,7 @@ struct Bufs {
     int* active;
     int* iters;
     int* status;
+    int* pend;      // [Bp] line-search winner index still to be applied by the APPLY pass (0 = nothing pending)
     double* cost_trace;   // [nb_iter][Bp] or null
     double* alpha_trace;  // [nb_iter][Bp] or null
     // augmented Lagrangian (shared constraint rows, per-instance multipliers)
@@ -35,12 +36,19 @@ struct Bufs {
 
 struct FwdArgs {
     int it, line_search, early_stop, do_update, nb_iter;
+    int n_alpha;  // number of step sizes 1, 1/2, ... the line search may try (11 for alpha_floor = 1e-3)
     double penalty_roll, penalty_update;
 };
 
-enum { KER_INIT = 0, KER_BACKWARD = 1, KER_FORWARD = 2 };
+// v1 (one lane per instance, generic): KER_INIT, KER_BACKWARD, KER_FORWARD
+// v2: KER_FWD_SPEC  = all n_alpha line-search trials of an instance at once (16 lanes per instance), K read once
+//     KER_FWD_APPLY = re-roll the winning step size for the instances whose winner was not alpha = 1
+//     KER_AL_UPDATE = multiplier update on the accepted trajectory
+//     KER_BACKWARD_SI = closed-form Riccati step for single-integrator dynamics (PosOrn, nb_deriv = 1)
+enum { KER_INIT = 0, KER_BACKWARD = 1, KER_FORWARD = 2, KER_FWD_SPEC = 3, KER_FWD_APPLY = 4, KER_AL_UPDATE = 5, KER_BACKWARD_SI = 6 };
 
 void launch_solver(int kind, int nd, int which, bool al, const Bufs& a, int B, hipStream_t st, const FwdArgs& f);
+void launch_solver_v2(int kind, int nd, int which, bool al, const Bufs& a, int B, int T, hipStream_t st, const FwdArgs& f);
 void launch_fx_all(int kind, int nd, const Bufs& a, int B, int T, double* out, hipStream_t st);
 void launch_to_soa(const double* src, double* dst, int B, int Bp, int rows, hipStream_t st);
 void launch_from_soa(const double* src, double* dst, int B, int Bp, int rows, hipStream_t st);

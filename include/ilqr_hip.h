@@ -176,7 +176,8 @@ int ilqr_fk_batch(ilqr_ctx* ctx, const ilqr_problem_desc* desc, int n, const dou
 #define ILQR_PROF_BACKWARD 1
 #define ILQR_PROF_FORWARD 2
 #define ILQR_PROF_OTHER 3
-#define ILQR_PROF_COUNT 4
+#define ILQR_PROF_APPLY 4 /* second forward pass: re-roll of the winning step size */
+#define ILQR_PROF_COUNT 5
 int ilqr_profile_enable(ilqr_ctx* ctx, int on);
 int ilqr_profile_reset(ilqr_ctx* ctx);
 int ilqr_profile_get(ilqr_ctx* ctx, int which, double* total_ms, int* launches);

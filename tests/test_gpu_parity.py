@@ -14,6 +14,14 @@ pytestmark = pytest.mark.gpu
 COST_RTOL = 1e-4
 
 
+@pytest.fixture(autouse=True, params=["v2", "v1"])
+def hip_path(request, monkeypatch):
+    """Every test runs on both kernel sets: v2 = alpha-parallel line search + closed-form single-integrator sweep
+    (default), v1 = generic lane-per-instance kernels (ILQR_HIP_PATH is read by the library at every solve)."""
+    monkeypatch.setenv("ILQR_HIP_PATH", request.param)
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def ctx():
     from ilqr_planner_amd import capi
