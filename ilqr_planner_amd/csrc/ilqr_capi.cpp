@@ -307,6 +307,7 @@ extern "C" int ilqr_problem_create(ilqr_ctx* c, const ilqr_problem_desc* d, int 
     rc |= dalloc(p, &b.iters, Bp);
     rc |= dalloc(p, &b.status, Bp);
     rc |= dalloc(p, &b.pend, Bp);
+    rc |= dalloc(p, &b.kpd, (size_t)(d->n_kp > 0 ? d->n_kp : 1) * (NX + NX * NX) * Bp);
     if (rc) { ilqr_problem_destroy(p); return 1; }
     b.U0 = U0; b.q0 = q0; b.dq0 = dq0; b.kp_tg = tg; b.desc = p->ddesc;
     if (hipMemcpyAsync(p->ddesc, &p->hdesc, sizeof(DevDesc), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
@@ -462,10 +463,10 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
     if (line_search) { double al_ = 1.0; while (al_ > p->desc.alpha_floor && n_alpha < 64) { al_ *= 0.5; n_alpha++; } }
     const int path = path_choice();
     const bool fwd_tile = (path != 1) && n_alpha <= 16;
-    const bool bwd_si = (path == 2) && kind == ILQR_SYS_POS_ORN && nd == 1 && (!al || p->con_state_only);
+    const bool bwd_si = (path == 2) && backward_si_supported(kind, nd, al, p->bufs.m, p->bufs.per_step, p->con_state_only);
     FwdArgs f;
     std::memset(&f, 0, sizeof(f));
-    f.line_search = line_search; f.early_stop = early_stop; f.nb_iter = nb_iter; f.penalty_roll = penalty; f.n_alpha = n_alpha;
+    f.line_search = line_search; f.early_stop = early_stop; f.nb_iter = nb_iter; f.penalty_roll = penalty; f.n_alpha = n_alpha; f.al = al ? 1 : 0; f.n_kp = p->desc.n_kp;
     {
         ProfScope ps(c, ILQR_PROF_ROLLOUT);
         launch_solver(kind, nd, KER_INIT, al, p->bufs, p->B, c->stream, f);
@@ -473,6 +474,10 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
     HIPCHK(c, hipGetLastError());
     for (int it = 0; it < nb_iter; it++) {
         {
+            if (bwd_si) {
+                ProfScope ps(c, ILQR_PROF_OTHER);
+                launch_solver_v2(kind, nd, KER_KP_DERIVS, al, p->bufs, p->B, p->T, c->stream, f);
+            }
             ProfScope ps(c, ILQR_PROF_BACKWARD);
             if (bwd_si) launch_solver_v2(kind, nd, KER_BACKWARD_SI, al, p->bufs, p->B, p->T, c->stream, f);
             else launch_solver(kind, nd, KER_BACKWARD, al, p->bufs, p->B, c->stream, f);
@@ -491,7 +496,7 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
                 ProfScope ps(c, ILQR_PROF_APPLY);
                 launch_solver_v2(kind, nd, KER_FWD_APPLY, al, p->bufs, p->B, p->T, c->stream, f);
             }
-            if (f.do_update) {
+            if (al) {  // active-set weights of the accepted trajectory (+ multiplier update every `lag` iterations)
                 ProfScope ps(c, ILQR_PROF_OTHER);
                 launch_solver_v2(kind, nd, KER_AL_UPDATE, al, p->bufs, p->B, p->T, c->stream, f);
             }

@@ -23,6 +23,7 @@ struct Bufs {
     int* active;
     int* iters;
     int* status;
+    double* kpd;    // [n_kp][NX + NX*NX][Bp] l_x | l_xx of the keypoint steps of the current trajectory (k_kp_derivs)
     int* pend;      // [Bp] line-search winner index still to be applied by the APPLY pass (0 = nothing pending)
     double* cost_trace;   // [nb_iter][Bp] or null
     double* alpha_trace;  // [nb_iter][Bp] or null
@@ -36,6 +37,8 @@ struct Bufs {
 
 struct FwdArgs {
     int it, line_search, early_stop, do_update, nb_iter;
+    int n_kp;     // number of keypoints (grid of KER_KP_DERIVS)
+    int al;       // 1 = AL_ILQR semantics (early stop without the cost test)
     int n_alpha;  // number of step sizes 1, 1/2, ... the line search may try (11 for alpha_floor = 1e-3)
     double penalty_roll, penalty_update;
 };
@@ -45,9 +48,11 @@ struct FwdArgs {
 //     KER_FWD_APPLY = re-roll the winning step size for the instances whose winner was not alpha = 1
 //     KER_AL_UPDATE = multiplier update on the accepted trajectory
 //     KER_BACKWARD_SI = closed-form Riccati step for single-integrator dynamics (PosOrn, nb_deriv = 1)
-enum { KER_INIT = 0, KER_BACKWARD = 1, KER_FORWARD = 2, KER_FWD_SPEC = 3, KER_FWD_APPLY = 4, KER_AL_UPDATE = 5, KER_BACKWARD_SI = 6 };
+//     KER_KP_DERIVS = l_x, l_xx at the keypoint steps (FK + Jacobian), one lane per (instance, keypoint), feeding KER_BACKWARD_SI
+enum { KER_INIT = 0, KER_BACKWARD = 1, KER_FORWARD = 2, KER_FWD_SPEC = 3, KER_FWD_APPLY = 4, KER_AL_UPDATE = 5, KER_BACKWARD_SI = 6, KER_KP_DERIVS = 7 };
 
 void launch_solver(int kind, int nd, int which, bool al, const Bufs& a, int B, hipStream_t st, const FwdArgs& f);
+bool backward_si_supported(int kind, int nd, bool al, int m, int per_step, bool con_state_only);
 void launch_solver_v2(int kind, int nd, int which, bool al, const Bufs& a, int B, int T, hipStream_t st, const FwdArgs& f);
 void launch_fx_all(int kind, int nd, const Bufs& a, int B, int T, double* out, hipStream_t st);
 void launch_to_soa(const double* src, double* dst, int B, int Bp, int rows, hipStream_t st);

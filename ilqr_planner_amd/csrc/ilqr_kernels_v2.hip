@@ -10,7 +10,10 @@
 //                  ballot exactly as the do/while would have (first alpha whose cost is below cost0 and not NaN,
 //                  else the last one).  B = 4096 gives 256 workgroups = one per CU, 1024 waves.
 //                  APPLY mode re-rolls the winning alpha for the instances whose winner was not alpha = 1.
-// k_al_update      multiplier update of AL-ILQR.cpp:202-208 on the accepted trajectory, one lane per (instance, k).
+// k_al_post        AL bookkeeping on the ACCEPTED trajectory, one lane per (instance, k): the active-set weights
+//                  penalty * I_k the next backward sweep needs (AL-ILQR.cpp:21-44,190 -- every trial overwrites them, so
+//                  only the accepted trial's values survive in the reference too) and, every lag_update_step
+//                  iterations, the multiplier update (AL-ILQR.cpp:202-208).  Keeps the rollout kernels free of AL.
 // k_backward_si    backward Riccati sweep specialised to single-integrator dynamics (PosOrnPlannerSys nb_deriv = 1:
 //                  A = I, B = dt I, l_ux = 0), one lane per instance.  With S = Quu + reg I = D + dt^2 P,
 //                  D = R + reg I and M = S^-1 the reference's update collapses, exactly, to
@@ -21,14 +24,48 @@
 //                  (K'QuuK + K'Qux = -reg K'K because (Quu + reg I) K = -Qux; Qxu K = dt P K).  One SPD inverse
 //                  (LDL^T, no pivoting needed) and one symmetric 7x7x7 product replace the partial-pivot LU and
 //                  five dense products of the generic sweep (ilqr_kernels.hip k_backward), all in registers.
+// Everything a loop needs from the shared descriptor is copied into registers before the loop: the compiler cannot
+// prove that the trajectory stores do not alias the descriptor and would otherwise re-issue scalar loads every step.
 #include "ilqr_kernels.hpp"
 #include "ilqr_step.hpp"
 
 namespace ilqr {
 
+// Workgroup barrier that only drains LDS traffic: __syncthreads() also emits s_waitcnt vmcnt(0), which would wait for
+// the global prefetches issued several timesteps ahead and serialise every step behind an HBM round trip.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// joint/velocity limits held in registers (inspectJointLimit, System.cpp:121-142)
+template <int NX>
+struct LimRegs {
+    int on;
+    double penalty;
+    double smax[NX], smin[NX];
+    int lw[NX];
+    __device__ __forceinline__ void load(const DevDesc& d) {
+        on = d.limits_set;
+        penalty = d.penalty;
+        UNR for (int i = 0; i < NX; i++) { smax[i] = d.smax[i]; smin[i] = d.smin[i]; lw[i] = d.lw[i]; }
+    }
+    __device__ __forceinline__ double cost(const double* x) const {
+        double a = 0;
+        if (on) {
+            UNR for (int i = 0; i < NX; i++) {
+                if (lw[i] != 0) {
+                    double qv = 0, L = 0;
+                    if (x[i] > smax[i]) { qv = smax[i] - x[i]; L = penalty; }
+                    else if (x[i] < smin[i]) { qv = smin[i] - x[i]; L = penalty; }
+                    a += qv * L * qv;
+                }
+            }
+        }
+        return a;
+    }
+};
+
 // ------------------------------------------------------------------------------------------------ forward, alpha-parallel
 
-template <class S, bool AL, bool APPLY>
+template <class S, bool APPLY>
 __global__ __launch_bounds__(256) void k_forward_tile(Bufs a, FwdArgs f) {
     constexpr int NX = S::NX, NU = S::NU, NK = NU * NX;
     constexpr int NC = NK + NU + NX + NU;          // doubles per instance-step: K | d | xbar | ubar
@@ -42,15 +79,15 @@ __global__ __launch_bounds__(256) void k_forward_tile(Bufs a, FwdArgs f) {
     const DevDesc& d = *a.desc;
     const int tid = threadIdx.x, il = tid >> 4, ai = tid & 15;
     const int b0 = blockIdx.x * 16, b = b0 + il;
-    const int Bp = d.Bp, T = d.T;
+    const int Bp = d.Bp, T = d.T, B = d.B;
 
     bool part;
     double alpha;
     if (!APPLY) {
-        part = (b < d.B) && a.active[b] && (ai < f.n_alpha);
+        part = (b < B) && a.active[b] && (ai < f.n_alpha);
         alpha = ldexp(1.0, -ai);
     } else {
-        const int w = (b < d.B) ? a.pend[b] : 0;
+        const int w = (b < B) ? a.pend[b] : 0;
         part = (w > 0) && (ai == 0);
         alpha = ldexp(1.0, -w);
     }
@@ -58,11 +95,20 @@ __global__ __launch_bounds__(256) void k_forward_tile(Bufs a, FwdArgs f) {
     const bool writer = part && (ai == 0);
     if (ai == 0) s_wr[il] = writer ? 1 : 0;
 
+    // descriptor -> registers
+    LimRegs<NX> lim;
+    lim.load(d);
+    const double dt_fixed = d.dt;
+    const int n_kp = d.n_kp;
+    int kp_next = (n_kp > 0) ? d.kp_t[0] : -1;
+
     // loader role: this thread always fetches for instance (tid & 15), components (tid >> 4) + 16 j
     const int li = tid & 15, lb = b0 + li, lc0 = tid >> 4;
     const int lcur = a.cur[lb];
     const double* Xc = a.X[lcur];
     const double* Uc = a.U[lcur];
+    const double* Kp = a.K;
+    const double* Dp = a.D;
     auto load_step = [&](int k, double* r) {
         UNR for (int j = 0; j < NLD; j++) {
             const int c = lc0 + 16 * j;
@@ -70,8 +116,8 @@ __global__ __launch_bounds__(256) void k_forward_tile(Bufs a, FwdArgs f) {
             if (c < NC && k < T - 1) {
                 const double* base;
                 int row;
-                if (c < NK) { base = a.K; row = k * NK + c; }
-                else if (c < NK + NU) { base = a.D; row = k * NU + (c - NK); }
+                if (c < NK) { base = Kp; row = k * NK + c; }
+                else if (c < NK + NU) { base = Dp; row = k * NU + (c - NK); }
                 else if (c < NK + NU + NX) { base = Xc; row = k * NX + (c - NK - NU); }
                 else { base = Uc; row = k * NU + (c - NK - NU - NX); }
                 r[j] = base[(size_t)row * Bp + lb];
@@ -84,22 +130,18 @@ __global__ __launch_bounds__(256) void k_forward_tile(Bufs a, FwdArgs f) {
             if (c < NC) s_in[buf][c][li] = r[j];
         }
     };
-
-    // writer role of the output stage: thread t < NO*16 stores component t>>4 of instance t&15
-    const int cur_b = (b < d.B) ? a.cur[b] : 0;
-    double* Xn = a.X[1 - lcur];  // for the store stage (instance li)
+    // output stage: thread t stores component (t >> 4) + 16 j of instance t & 15
+    double* Xn = a.X[1 - lcur];
     double* Un = a.U[1 - lcur];
     auto store_step = [&](int k, int buf) {  // x_k (k <= T-1), u_k (k <= T-2)
-        if (tid < NO * 16 && s_wr[li]) {
-            const int c = lc0;
+        if (s_wr[li]) {
             UNR for (int j = 0; j < (NO + 15) / 16; j++) {
-                const int cc = c + 16 * j;
+                const int cc = lc0 + 16 * j;
                 if (cc < NX) Xn[(size_t)(k * NX + cc) * Bp + lb] = s_out[buf][cc][li];
                 else if (cc < NO && k < T - 1) Un[(size_t)(k * NU + (cc - NX)) * Bp + lb] = s_out[buf][cc][li];
             }
         }
     };
-    (void)cur_b;
 
     double pre[PF][NLD];
     UNR for (int j = 0; j < PF; j++) load_step(j, pre[j]);
@@ -107,12 +149,12 @@ __global__ __launch_bounds__(256) void k_forward_tile(Bufs a, FwdArgs f) {
     double x[NX];
     if (part) init_state<S>(d, a, b, x);
     else { UNR for (int i = 0; i < NX; i++) x[i] = 0; }
-    const double cost0 = (b < d.B) ? a.cost[b] : 0.0;
+    const double cost0 = (b < B) ? a.cost[b] : 0.0;
     double newCost = 0, dun = 0;
     int kpi = 0;
 
     stage_step(0, pre[0]);
-    __syncthreads();
+    lds_barrier();
 
     const int nsteps = T - 1;
     for (int k0 = 0; k0 < nsteps; k0 += PF) {
@@ -120,12 +162,12 @@ __global__ __launch_bounds__(256) void k_forward_tile(Bufs a, FwdArgs f) {
             const int k = k0 + j;
             if (k < nsteps) {  // uniform
                 const int buf = k & 1;
-                // prefetch step k+PF into the slot just consumed, stage step k+1 (loaded PF-1 steps ago)
+                // stage step k+1 (loaded PF-1 steps ago), prefetch step k+PF into the slot just consumed
                 double nxt[NLD];
                 UNR for (int q = 0; q < NLD; q++) nxt[q] = pre[(j + 1) % PF][q];
                 load_step(k + PF, pre[j]);
                 if (part) {
-                    double u[NU], xn[NX], dx[NX];
+                    double u[NU], dx[NX];
                     UNR for (int i = 0; i < NX; i++) dx[i] = x[i] - s_in[buf][NK + NU + i][il];
                     double n2 = 0;
                     UNR for (int i = 0; i < NU; i++) {
@@ -139,22 +181,32 @@ __global__ __launch_bounds__(256) void k_forward_tile(Bufs a, FwdArgs f) {
                     if (writer) {
                         UNR for (int i = 0; i < NX; i++) s_out[buf][i][il] = x[i];
                         UNR for (int i = 0; i < NU; i++) s_out[buf][NX + i][il] = u[i];
-                        if (AL) {
-                            for (int r = 0; r < a.m; r++) {
-                                const double g = con_g<S>(a, k, r, x, u);
-                                const double lam = AT(a.lambda, k * a.m + r, b);
-                                AT(a.Is, k * a.m + r, b) = f.penalty_roll * ((g < 0 && lam == 0) ? 0.0 : 1.0);
-                            }
+                    }
+                    if (k == kp_next) {  // keypoint step (rare): task cost out of line
+                        double xt[NX], ut[NU];
+                        UNR for (int i = 0; i < NX; i++) xt[i] = x[i];
+                        UNR for (int i = 0; i < NU; i++) ut[i] = u[i];
+                        newCost += kp_cost_call<S>(&d, a.kp_tg, Bp, b, kpi, xt, ut);
+                        kpi++;
+                        kp_next = (kpi < n_kp) ? d.kp_t[kpi] : -1;
+                    }
+                    newCost += lim.cost(x);
+                    // dynamics step (SimulationInterface.cpp:19-31)
+                    const double dts = S::TM ? u[NU - 1] : 0.0;
+                    const double dt = S::TM ? dts * dts : dt_fixed;
+                    if (S::ND == 1) {
+                        UNR for (int i = 0; i < DOF; i++) x[i] = x[i] + (dt * u[i] + dt * dt / 2 * 0.0);
+                    } else {
+                        UNR for (int i = 0; i < DOF; i++) {
+                            const double v = x[DOF + i];
+                            x[i] = x[i] + (dt * v + dt * dt / 2 * u[i]);
+                            x[DOF + i] = v + dt * u[i];
                         }
                     }
-                    const bool iskp = (kpi < d.n_kp && d.kp_t[kpi] == k);
-                    newCost += stage_cost<S>(d, a, b, iskp ? kpi : -1, x, u);
-                    if (iskp) kpi++;
-                    dyn_step<S>(d, x, u, xn);
-                    UNR for (int i = 0; i < NX; i++) x[i] = xn[i];
+                    if (S::TM) x[NX - 1] = x[NX - 1] + dt;
                 }
                 stage_step(buf ^ 1, nxt);
-                __syncthreads();
+                lds_barrier();
                 store_step(k, buf);
             }
         }
@@ -164,12 +216,15 @@ __global__ __launch_bounds__(256) void k_forward_tile(Bufs a, FwdArgs f) {
         const int buf = nsteps & 1;
         if (part) {
             if (writer) { UNR for (int i = 0; i < NX; i++) s_out[buf][i][il] = x[i]; }
-            const bool iskp = (kpi < d.n_kp && d.kp_t[kpi] == T - 1);
-            double zu[NU];
-            UNR for (int i = 0; i < NU; i++) zu[i] = 0;
-            newCost += stage_cost<S>(d, a, b, iskp ? kpi : -1, x, zu);
+            if (kp_next == T - 1) {
+                double xt[NX], zu[NU];
+                UNR for (int i = 0; i < NX; i++) xt[i] = x[i];
+                UNR for (int i = 0; i < NU; i++) zu[i] = 0;
+                newCost += kp_cost_call<S>(&d, a.kp_tg, Bp, b, kpi, xt, zu);
+            }
+            newCost += lim.cost(x);
         }
-        __syncthreads();
+        lds_barrier();
         store_step(T - 1, buf);
     }
 
@@ -201,15 +256,16 @@ __global__ __launch_bounds__(256) void k_forward_tile(Bufs a, FwdArgs f) {
         if (w == 0) a.cur[b] = 1 - a.cur[b];  // the speculatively written alpha = 1 trajectory is the accepted one
         else a.pend[b] = w;
         bool stop = f.early_stop && (walpha * sqrt(wdun) < d.stop_tol);
-        if (!AL) stop = stop && (wcost < 1e-3);
+        if (!f.al) stop = stop && (wcost < 1e-3);  // ILQRRecursive.cpp:174 vs AL-ILQR.cpp:225
         if (stop) a.active[b] = 0;
     }
 }
 
-// multipliers: lambda <- max(0, lambda + penalty * g(x_k, u_k)) on the accepted trajectory of the instances that ran
-// iteration `it` (AL-ILQR.cpp:202-208); one lane per (instance, timestep)
+// AL bookkeeping on the accepted trajectory of the instances that ran iteration `it`:
+//   I_k      = penalty_roll * (g<0 && lambda==0 ? 0 : 1)          with the multipliers BEFORE the update
+//   lambda_k = max(0, lambda_k + penalty_update * g)               only on update iterations
 template <class S>
-__global__ __launch_bounds__(256) void k_al_update(Bufs a, FwdArgs f) {
+__global__ __launch_bounds__(256) void k_al_post(Bufs a, FwdArgs f) {
     const DevDesc& d = *a.desc;
     const int b = blockIdx.x * 256 + threadIdx.x;
     const int k = blockIdx.y;
@@ -222,8 +278,36 @@ __global__ __launch_bounds__(256) void k_al_update(Bufs a, FwdArgs f) {
     UNR for (int i = 0; i < S::NU; i++) u[i] = AT(a.U[cur], k * S::NU + i, b);
     for (int r = 0; r < a.m; r++) {
         const double g = con_g<S>(a, k, r, x, u);
-        const double v = AT(a.lambda, k * a.m + r, b) + f.penalty_update * g;
-        AT(a.lambda, k * a.m + r, b) = v > 0 ? v : 0;
+        const double lam = AT(a.lambda, k * a.m + r, b);
+        AT(a.Is, k * a.m + r, b) = f.penalty_roll * ((g < 0 && lam == 0) ? 0.0 : 1.0);
+        if (f.do_update) {
+            const double v = lam + f.penalty_update * g;
+            AT(a.lambda, k * a.m + r, b) = v > 0 ? v : 0;
+        }
+    }
+}
+
+// l_x, l_xx of the keypoint steps (System::cost_x / cost_xx incl. the limit terms) for the current trajectory, one lane per
+// (instance, keypoint).  Keeps FK, the quaternion log map and J'QJ out of the sequential sweep: the sweep only loads
+// NX + NX*NX doubles at the (two) keypoint steps.
+template <class S>
+__global__ __launch_bounds__(64) void k_kp_derivs(Bufs a) {
+    constexpr int NX = S::NX;
+    const DevDesc& d = *a.desc;
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    const int kpi = blockIdx.y;
+    if (b >= d.B) return;
+    if (!a.active[b]) return;
+    const int Bp = d.Bp;
+    const int k = d.kp_t[kpi];
+    const double* X = a.X[a.cur[b]];
+    double x[NX], lxx[NX][NX], lx[NX];
+    UNR for (int i = 0; i < NX; i++) x[i] = AT(X, k * NX + i, b);
+    stage_derivs<S>(d, a, b, x, kpi, lxx, lx);
+    double* out = a.kpd + (size_t)kpi * (NX + NX * NX) * Bp;
+    UNR for (int i = 0; i < NX; i++) {
+        AT(out, i, b) = lx[i];
+        UNR for (int j = 0; j < NX; j++) AT(out, NX + i * NX + j, b) = lxx[i][j];
     }
 }
 
@@ -232,10 +316,12 @@ __global__ __launch_bounds__(256) void k_al_update(Bufs a, FwdArgs f) {
 __device__ __forceinline__ constexpr int sym(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 
 // AL rows must not touch the controls for the closed form (checked on the host); they then only add to l_x, l_xx.
-template <bool AL>
+// MR = constraint rows kept in registers (m <= MR and per_step == 0), 0 = no AL.
+template <int MR>
 __global__ __launch_bounds__(64) void k_backward_si(Bufs a) {
     using S = Sys<0, 1>;
     constexpr int N = 7, NS = N * (N + 1) / 2;
+    constexpr int MRR = MR > 0 ? MR : 1;
     const DevDesc& d = *a.desc;
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= d.B) return;
@@ -244,43 +330,85 @@ __global__ __launch_bounds__(64) void k_backward_si(Bufs a) {
     const int cur = a.cur[b];
     const double* X = a.X[cur];
     const double* U = a.U[cur];
+    double* Kp = a.K;
+    double* Dp = a.D;
     const double dt = d.dt, idt = 1.0 / dt, idt2 = idt * idt, reg = d.reg;
-    double Dg[N];
-    UNR for (int i = 0; i < N; i++) Dg[i] = d.R_diag[i] + reg;
+    double Dg[N], Rd[N];
+    UNR for (int i = 0; i < N; i++) { Rd[i] = d.R_diag[i]; Dg[i] = Rd[i] + reg; }
+    LimRegs<N> lim;
+    lim.load(d);
+    // constraint rows (state part) and right-hand sides
+    const int m = a.m;
+    double Ax[MRR][N], bb[MRR];
+    UNR for (int r = 0; r < MRR; r++) {
+        bb[r] = 0;
+        UNR for (int i = 0; i < N; i++) Ax[r][i] = 0;
+        if (MR > 0 && r < m) {
+            bb[r] = a.conb[r];
+            UNR for (int i = 0; i < N; i++) Ax[r][i] = a.conA[(size_t)r * 2 * N + i];
+        }
+    }
+    const double* lamp = a.lambda;
+    const double* Isp = a.Is;
 
     double P[NS], p[N], x[N], u[N];
     int kpi = d.n_kp - 1;
+    int kp_next = (kpi >= 0) ? d.kp_t[kpi] : -1;
     // terminal: P = l_xx(x_{T-1}), p = l_x(x_{T-1})   (no constraint on the final state, AL-ILQR.cpp:96)
+    const double* kpd = a.kpd;
     {
         UNR for (int i = 0; i < N; i++) x[i] = AT(X, (T - 1) * N + i, b);
-        double lxx[N][N], lx[N];
-        const bool iskp = (kpi >= 0 && d.kp_t[kpi] == T - 1);
-        stage_derivs<S>(d, a, b, x, iskp ? kpi : -1, lxx, lx);
-        if (iskp) kpi--;
-        UNR for (int i = 0; i < N; i++) {
-            p[i] = lx[i];
-            UNR for (int j = 0; j <= i; j++) P[sym(i, j)] = lxx[i][j];
+        UNR for (int i = 0; i < N; i++) p[i] = 0;
+        UNR for (int i = 0; i < NS; i++) P[i] = 0;
+        if (kp_next == T - 1) {  // l_x | l_xx precomputed by k_kp_derivs (incl. limits)
+            const double* src = kpd + (size_t)kpi * (N + N * N) * Bp;
+            UNR for (int i = 0; i < N; i++) {
+                p[i] = AT(src, i, b);
+                UNR for (int j = 0; j <= i; j++) P[sym(i, j)] = AT(src, N + i * N + j, b);
+            }
+            kpi--;
+            kp_next = (kpi >= 0) ? d.kp_t[kpi] : -1;
+        } else if (lim.on) {
+            UNR for (int i = 0; i < N; i++) {
+                if (lim.lw[i] != 0) {
+                    double qv = 0, L = 0;
+                    if (x[i] > lim.smax[i]) { qv = lim.smax[i] - x[i]; L = lim.penalty; }
+                    else if (x[i] < lim.smin[i]) { qv = lim.smin[i] - x[i]; L = lim.penalty; }
+                    p[i] += -L * qv;
+                    P[sym(i, i)] += L * L;
+                }
+            }
         }
     }
-    // prefetch of the next timestep's xbar, ubar
-    double xn_[N], un_[N];
+    // one-step-ahead prefetch of xbar, ubar, lambda, I
+    double xn_[N], un_[N], lamn[MRR], Isn[MRR];
     UNR for (int i = 0; i < N; i++) { xn_[i] = AT(X, (T - 2) * N + i, b); un_[i] = AT(U, (T - 2) * N + i, b); }
+    UNR for (int r = 0; r < MRR; r++) {
+        lamn[r] = 0; Isn[r] = 0;
+        if (MR > 0 && r < m) { lamn[r] = AT(lamp, (T - 2) * m + r, b); Isn[r] = AT(Isp, (T - 2) * m + r, b); }
+    }
 
     for (int k = T - 2; k >= 0; k--) {
+        double lam[MRR], Isk[MRR];
         UNR for (int i = 0; i < N; i++) { x[i] = xn_[i]; u[i] = un_[i]; }
-        if (k > 0) { UNR for (int i = 0; i < N; i++) { xn_[i] = AT(X, (k - 1) * N + i, b); un_[i] = AT(U, (k - 1) * N + i, b); } }
+        UNR for (int r = 0; r < MRR; r++) { lam[r] = lamn[r]; Isk[r] = Isn[r]; }
+        if (k > 0) {
+            UNR for (int i = 0; i < N; i++) { xn_[i] = AT(X, (k - 1) * N + i, b); un_[i] = AT(U, (k - 1) * N + i, b); }
+            UNR for (int r = 0; r < MRR; r++)
+                if (MR > 0 && r < m) { lamn[r] = AT(lamp, (k - 1) * m + r, b); Isn[r] = AT(Isp, (k - 1) * m + r, b); }
+        }
 
         // S = D + dt^2 P   (= Quu + reg I)
         double Sm[NS];
         UNR for (int i = 0; i < N; i++)
             UNR for (int j = 0; j <= i; j++) Sm[sym(i, j)] = dt * (dt * P[sym(i, j)]) + ((i == j) ? Dg[i] : 0.0);
-        // LDL^T:  S = L diag(e) L^T  (L unit lower, stored in Sm below the diagonal; 1/e on the diagonal)
+        // LDL^T:  S = L diag(e) L^T  (L unit lower below the diagonal of Sm, e on its diagonal, ie = 1/e)
         double ie[N];
         UNR for (int j = 0; j < N; j++) {
             double le[N];  // L_jq * e_q
             double ej = Sm[sym(j, j)];
             UNR for (int q = 0; q < j; q++) {
-                le[q] = Sm[sym(j, q)] * Sm[sym(q, q)];  // the diagonal slot holds e_q once column q is done
+                le[q] = Sm[sym(j, q)] * Sm[sym(q, q)];
                 ej -= Sm[sym(j, q)] * le[q];
             }
             Sm[sym(j, j)] = ej;
@@ -303,15 +431,18 @@ __global__ __launch_bounds__(64) void k_backward_si(Bufs a) {
         }
         // M = S^-1 = Li^T diag(1/e) Li  (symmetric)
         double M[NS];
-        UNR for (int i = 0; i < N; i++)
+        UNR for (int i = 0; i < N; i++) {
+            double ti[N];  // column i of diag(1/e) Li
+            UNR for (int q = i; q < N; q++) ti[q] = Li[sym(q, i)] * ie[q];
             UNR for (int j = 0; j <= i; j++) {
                 double s = 0;
-                UNR for (int q = i; q < N; q++) s += (Li[sym(q, i)] * ie[q]) * Li[sym(q, j)];
+                UNR for (int q = i; q < N; q++) s += ti[q] * Li[sym(q, j)];
                 M[sym(i, j)] = s;
             }
+        }
         // Qu = R u + dt p ; dv = -M Qu ; Md = M dv
         double Qu[N], dv[N], Md[N];
-        UNR for (int i = 0; i < N; i++) Qu[i] = d.R_diag[i] * u[i] + dt * p[i];
+        UNR for (int i = 0; i < N; i++) Qu[i] = Rd[i] * u[i] + dt * p[i];
         UNR for (int i = 0; i < N; i++) {
             double s = 0;
             UNR for (int j = 0; j < N; j++) s += M[sym(i, j)] * Qu[j];
@@ -325,47 +456,44 @@ __global__ __launch_bounds__(64) void k_backward_si(Bufs a) {
         // K = (M D - I)/dt ; store K, d
         UNR for (int i = 0; i < N; i++) {
             UNR for (int j = 0; j < N; j++)
-                AT(a.K, k * N * N + i * N + j, b) = (M[sym(i, j)] * Dg[j] - ((i == j) ? 1.0 : 0.0)) * idt;
-            AT(a.D, k * N + i, b) = dv[i];
+                AT(Kp, k * N * N + i * N + j, b) = (M[sym(i, j)] * Dg[j] - ((i == j) ? 1.0 : 0.0)) * idt;
+            AT(Dp, k * N + i, b) = dv[i];
         }
         // stage derivatives (keypoint / limits / AL rows)
         double lx[N];
         UNR for (int i = 0; i < N; i++) lx[i] = 0;
         double lxxs[NS];
         UNR for (int i = 0; i < NS; i++) lxxs[i] = 0;
-        {
-            const bool iskp = (kpi >= 0 && d.kp_t[kpi] == k);
-            if (iskp) {
-                double lxx[N][N], lxf[N];
-                stage_derivs<S>(d, a, b, x, kpi, lxx, lxf);  // includes the limit terms
-                UNR for (int i = 0; i < N; i++) {
-                    lx[i] = lxf[i];
-                    UNR for (int j = 0; j <= i; j++) lxxs[sym(i, j)] = lxx[i][j];
-                }
-                kpi--;
-            } else if (d.limits_set) {
-                UNR for (int i = 0; i < N; i++) {
-                    if (d.lw[i] != 0) {
-                        double qv = 0, L = 0;
-                        if (x[i] > d.smax[i]) { qv = d.smax[i] - x[i]; L = d.penalty; }
-                        else if (x[i] < d.smin[i]) { qv = d.smin[i] - x[i]; L = d.penalty; }
-                        lx[i] += -L * qv;
-                        lxxs[sym(i, i)] += L * L;
-                    }
+        if (k == kp_next) {  // rare: l_x | l_xx precomputed by k_kp_derivs (incl. the limit terms)
+            const double* src = kpd + (size_t)kpi * (N + N * N) * Bp;
+            UNR for (int i = 0; i < N; i++) {
+                lx[i] = AT(src, i, b);
+                UNR for (int j = 0; j <= i; j++) lxxs[sym(i, j)] = AT(src, N + i * N + j, b);
+            }
+            kpi--;
+            kp_next = (kpi >= 0) ? d.kp_t[kpi] : -1;
+        } else if (lim.on) {
+            UNR for (int i = 0; i < N; i++) {
+                if (lim.lw[i] != 0) {
+                    double qv = 0, L = 0;
+                    if (x[i] > lim.smax[i]) { qv = lim.smax[i] - x[i]; L = lim.penalty; }
+                    else if (x[i] < lim.smin[i]) { qv = lim.smin[i] - x[i]; L = lim.penalty; }
+                    lx[i] += -L * qv;
+                    lxxs[sym(i, i)] += L * L;
                 }
             }
         }
-        if (AL) {
-            const int ns = 2 * N;
-            for (int r = 0; r < a.m; r++) {
-                const double* Ar = a.conA + ((size_t)(a.per_step ? k : 0) * a.m + r) * ns;
-                const double Ik = AT(a.Is, k * a.m + r, b);
-                const double lam = AT(a.lambda, k * a.m + r, b);
-                const double g = con_g<S>(a, k, r, x, u);
-                const double wv = lam + Ik * g;
-                UNR for (int i = 0; i < N; i++) {
-                    UNR for (int j = 0; j <= i; j++) lxxs[sym(i, j)] += Ar[i] * Ik * Ar[j];
-                    lx[i] += Ar[i] * wv;
+        if (MR > 0) {  // AL-ILQR.cpp:110-134 with c_u = 0: only Qxx, Qx change
+            UNR for (int r = 0; r < MRR; r++) {
+                if (r < m) {
+                    double g = 0;
+                    UNR for (int i = 0; i < N; i++) g += Ax[r][i] * x[i];
+                    g -= bb[r];
+                    const double wv = lam[r] + Isk[r] * g;
+                    UNR for (int i = 0; i < N; i++) {
+                        UNR for (int j = 0; j <= i; j++) lxxs[sym(i, j)] += Ax[r][i] * Isk[r] * Ax[r][j];
+                        lx[i] += Ax[r][i] * wv;
+                    }
                 }
             }
         }
@@ -388,34 +516,44 @@ __global__ __launch_bounds__(64) void k_backward_si(Bufs a) {
 // ------------------------------------------------------------------------------------------------ launchers
 
 template <class S>
-static void launch_v2_kernel(int which, bool al, const Bufs& a, int B, int T, hipStream_t st, const FwdArgs& f) {
+static void launch_v2_kernel(int which, const Bufs& a, int B, int T, hipStream_t st, const FwdArgs& f) {
     const dim3 gridT((B + 15) / 16), blockT(256);
     switch (which) {
         case KER_FWD_SPEC:
-            if (al) hipLaunchKernelGGL((k_forward_tile<S, true, false>), gridT, blockT, 0, st, a, f);
-            else hipLaunchKernelGGL((k_forward_tile<S, false, false>), gridT, blockT, 0, st, a, f);
+            hipLaunchKernelGGL((k_forward_tile<S, false>), gridT, blockT, 0, st, a, f);
             break;
         case KER_FWD_APPLY:
-            if (al) hipLaunchKernelGGL((k_forward_tile<S, true, true>), gridT, blockT, 0, st, a, f);
-            else hipLaunchKernelGGL((k_forward_tile<S, false, true>), gridT, blockT, 0, st, a, f);
+            hipLaunchKernelGGL((k_forward_tile<S, true>), gridT, blockT, 0, st, a, f);
             break;
         case KER_AL_UPDATE:
-            hipLaunchKernelGGL((k_al_update<S>), dim3((B + 255) / 256, T - 1), dim3(256), 0, st, a, f);
+            hipLaunchKernelGGL((k_al_post<S>), dim3((B + 255) / 256, T - 1), dim3(256), 0, st, a, f);
+            break;
+        case KER_KP_DERIVS:
+            if (f.n_kp > 0) hipLaunchKernelGGL((k_kp_derivs<S>), dim3((B + 63) / 64, f.n_kp), dim3(64), 0, st, a);
             break;
     }
+}
+
+// closed-form sweep: usable for PosOrn nb_deriv=1 when no constraint row touches the controls, rows are shared over k
+// and there are at most 4 of them (they live in registers)
+bool backward_si_supported(int kind, int nd, bool al, int m, int per_step, bool con_state_only) {
+    if (kind != 0 || nd != 1) return false;
+    if (!al) return true;
+    return con_state_only && per_step == 0 && m <= 4;
 }
 
 void launch_solver_v2(int kind, int nd, int which, bool al, const Bufs& a, int B, int T, hipStream_t st, const FwdArgs& f) {
     if (which == KER_BACKWARD_SI) {
         const dim3 grid((B + 63) / 64), block(64);
-        if (al) hipLaunchKernelGGL((k_backward_si<true>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((k_backward_si<false>), grid, block, 0, st, a);
+        if (!al) hipLaunchKernelGGL((k_backward_si<0>), grid, block, 0, st, a);
+        else if (a.m <= 1) hipLaunchKernelGGL((k_backward_si<1>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((k_backward_si<4>), grid, block, 0, st, a);
         return;
     }
-    if (kind == 0 && nd == 1) launch_v2_kernel<Sys<0, 1>>(which, al, a, B, T, st, f);
-    else if (kind == 0 && nd == 2) launch_v2_kernel<Sys<0, 2>>(which, al, a, B, T, st, f);
-    else if (kind == 1 && nd == 1) launch_v2_kernel<Sys<1, 1>>(which, al, a, B, T, st, f);
-    else launch_v2_kernel<Sys<1, 2>>(which, al, a, B, T, st, f);
+    if (kind == 0 && nd == 1) launch_v2_kernel<Sys<0, 1>>(which, a, B, T, st, f);
+    else if (kind == 0 && nd == 2) launch_v2_kernel<Sys<0, 2>>(which, a, B, T, st, f);
+    else if (kind == 1 && nd == 1) launch_v2_kernel<Sys<1, 1>>(which, a, B, T, st, f);
+    else launch_v2_kernel<Sys<1, 2>>(which, a, B, T, st, f);
 }
 
 }  // namespace ilqr

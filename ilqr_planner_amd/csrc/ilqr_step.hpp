@@ -159,6 +159,40 @@ ILQR_DEV double stage_cost(const DevDesc& d, const Bufs& a, int b, int kpi, cons
     return c;
 }
 
+// Out-of-line variants of the keypoint-step work for the hot loops of the v2 kernels: a keypoint occurs at ~2 of the
+// ~200 timesteps, so its code (FK with fp64 sincos, quaternion log map, J'QJ) is kept out of the loop body -- smaller
+// loop, lower register pressure.  Arguments are copies in private memory; only the rare path touches them.
+template <class S>
+__device__ __noinline__ double kp_cost_call(const DevDesc* d, const double* kp_tg, int Bp, int b, int kpi, const double* xt, const double* ut) {
+    double tg[S::NF];
+    UNR for (int i = 0; i < S::NF; i++) tg[i] = AT(kp_tg, kpi * S::NF + i, b);
+    return kp_cost<S>(*d, kpi, tg, xt, ut);
+}
+
+template <class S>
+ILQR_DEV double stage_cost_ool(const DevDesc& d, const Bufs& a, int b, int kpi, const double* x, const double* u) {
+    double c = 0;
+    if (kpi >= 0) {
+        double xt[S::NX], ut[S::NU];
+        UNR for (int i = 0; i < S::NX; i++) xt[i] = x[i];
+        UNR for (int i = 0; i < S::NU; i++) ut[i] = u[i];
+        c += kp_cost_call<S>(&d, a.kp_tg, d.Bp, b, kpi, xt, ut);
+    }
+    if (d.limits_set) c += limit_cost<S>(d, x);
+    return c;
+}
+
+// l_x, l_xx (dense, row-major NX x NX) of a keypoint step, out of line
+template <class S>
+__device__ __noinline__ void stage_derivs_call(const DevDesc* d, const Bufs* a, int b, int kpi, const double* xt, double* lxx_out, double* lx_out) {
+    double lxx[S::NX][S::NX], lx[S::NX];
+    stage_derivs<S>(*d, *a, b, xt, kpi, lxx, lx);
+    UNR for (int i = 0; i < S::NX; i++) {
+        lx_out[i] = lx[i];
+        UNR for (int j = 0; j < S::NX; j++) lxx_out[i * S::NX + j] = lxx[i][j];
+    }
+}
+
 template <class S>
 ILQR_DEV void init_state(const DevDesc& d, const Bufs& a, int b, double* x) {
     const int Bp = d.Bp;
