@@ -1,16 +1,396 @@
-// ilqr_batchcp.hip -- BatchILQRCP on the device (reference src/solver/BatchILQRCP.cpp:109-175)
+// ilqr_batchcp.hip -- BatchILQRCP on the device (reference src/solver/BatchILQRCP.cpp:109-175), one lane per instance.
+//
+// Gauss-Newton on the whole control sequence in the primitive basis u = PSI w.  Per iteration and instance:
+//   k_cp_linearize  System::fpBatch (System.cpp:181-211): rollout of the current u; at the keypoint steps the residual e,
+//                   C = J'QJ + L and r = J'Q e + L ql (limits on the PRE-step state, System.cpp:158).  Su (n_kp n_x x
+//                   n_u (T-1), BatchILQRCP.cpp:61-97) is never materialised: W = Su PSI obeys the same recurrence
+//                   W_{i+1} = A_i W_i + B_i PSI_i (W_1 = 0, the reference's shifted seeding: block j of PSI meets
+//                   B_j = dx_j/du_{j-1}, quirk D-1) and lives in LDS as an n_x x Kw tile per lane.  Also PSI'R u.
+//   k_cp_solve      H = sum_kp W'CW + PSI'R PSI,  g = sum_kp W'r - PSI'R u,  dw = H^-1 g by partial-pivot LU in LDS
+//                   (BatchILQRCP.cpp:129-133; the reference forms the inverse explicitly, same pivoting).
+//   k_cp_linesearch backtracking on the true cost (:138-158): u + alpha PSI dw, accept if cost < cost0 or alpha < 1e-3.
+// The contraction is a 14x14 (Kw x Kw) matrix per instance at the BASELINE config: far too small for an MFMA tile to
+// pay; it is VALU work and the pass is bound by the rollout, like the recursive solver.
 #include "ilqr_batchcp.hpp"
+
+#include <cstring>
+
+#include "ilqr_step.hpp"
 
 namespace ilqr {
 
-int batchcp_solve(BatchCPState&, const DevDesc&, Bufs&, int, int, int, int, const double*, int, int, int, hipStream_t, std::string& err) {
-    err = "ilqr_solve_batch_cp: not implemented in this build";
-    return 1;
+#define PSI(k, q) c.psi[(size_t)(k) * KWP + (q)]
+
+// dynamics step + the pieces of A, B the W recurrence needs (forwardPass, PosOrn*PlannerSys.cpp)
+template <class S>
+struct StepAB {
+    double dt, dts, hdt2;
+    double bc[S::NX];  // last column of B (time systems)
+};
+
+template <class S>
+ILQR_DEV void step_ab(const DevDesc& d, const double* x, const double* u, double* xn, StepAB<S>& ab) {
+    constexpr int NX = S::NX, NU = S::NU;
+    dyn_step<S>(d, x, u, xn);
+    ab.dts = S::TM ? u[NU - 1] : 0.0;
+    ab.dt = S::TM ? ab.dts * ab.dts : d.dt;
+    ab.hdt2 = ab.dt * ab.dt / 2;
+    if (S::TM) {
+        if (S::ND == 1) {
+            UNR for (int i = 0; i < DOF; i++) ab.bc[i] = 2 * ab.dts * u[i];
+        } else {
+            UNR for (int i = 0; i < DOF; i++) {
+                ab.bc[i] = 2 * ab.dts * xn[DOF + i] + 2 * ab.dts * ab.dts * ab.dts * u[i];  // velocity AFTER the step
+                ab.bc[DOF + i] = 2 * ab.dts * u[i];
+            }
+        }
+        ab.bc[NX - 1] = 2 * ab.dts;
+    }
 }
+
+// limits on a state: diag(L) and q (inspectJointLimit)
+template <class S>
+ILQR_DEV void limit_terms(const DevDesc& d, const double* x, double* Ld, double* q) {
+    UNR for (int i = 0; i < S::NX; i++) {
+        Ld[i] = 0;
+        q[i] = 0;
+        if (d.limits_set && d.lw[i] != 0) {
+            if (x[i] > d.smax[i]) { q[i] = d.smax[i] - x[i]; Ld[i] = d.penalty; }
+            else if (x[i] < d.smin[i]) { q[i] = d.smin[i] - x[i]; Ld[i] = d.penalty; }
+        }
+    }
+}
+
+template <class S, int KWP>
+__global__ __launch_bounds__(64) void k_cp_linearize(Bufs a, CPArgs c) {
+    constexpr int NX = S::NX, NU = S::NU;
+    extern __shared__ double lds[];
+    const DevDesc& d = *a.desc;
+    const int lane = threadIdx.x, b = blockIdx.x * 64 + lane;
+    if (b >= d.B || !a.active[b]) return;
+    const int Bp = d.Bp, T = d.T;
+#define WL(r, q) lds[((r) * KWP + (q)) * 64 + lane]
+    for (int i = 0; i < NX * KWP; i++) lds[i * 64 + lane] = 0;
+    double x[NX], xp[NX], u[NU], gu[KWP];
+    UNR for (int q = 0; q < KWP; q++) gu[q] = 0;
+    init_state<S>(d, a, b, x);
+    UNR for (int i = 0; i < NX; i++) xp[i] = x[i];
+    double cost_e = 0, cost_u = 0, cost_l = 0;
+    int kpi = 0;
+    const double* U = a.U[0];
+
+    auto record = [&](int i) {  // keypoint kpi sits at step i: x = x_i, xp = x_{i-1}
+        double lxx[NX][NX], lx[NX], Ld[NX], ql[NX];
+        stage_derivs<S, false>(d, a, b, x, kpi, lxx, lx);  // lxx = J'QJ, lx = -J'Q e
+        if (i > 0) limit_terms<S>(d, xp, Ld, ql);
+        else { UNR for (int r = 0; r < NX; r++) { Ld[r] = 0; ql[r] = 0; } }
+        double tg[S::NF];
+        UNR for (int r = 0; r < S::NF; r++) tg[r] = AT(a.kp_tg, kpi * S::NF + r, b);
+        cost_e += kp_cost<S>(d, kpi, tg, x, nullptr);
+        UNR for (int r = 0; r < NX; r++) cost_l += ql[r] * Ld[r] * ql[r];
+        double* Ck = c.Ckp + (size_t)kpi * NX * NX * Bp;
+        double* rk = c.rkp + (size_t)kpi * NX * Bp;
+        double* Wk = c.Wkp + (size_t)kpi * NX * KWP * Bp;
+        UNR for (int r = 0; r < NX; r++) {
+            UNR for (int s = 0; s < NX; s++) AT(Ck, r * NX + s, b) = lxx[r][s] + ((r == s) ? Ld[r] : 0.0);
+            AT(rk, r, b) = -lx[r] + Ld[r] * ql[r];
+        }
+        for (int e = 0; e < NX * KWP; e++) AT(Wk, e, b) = lds[e * 64 + lane];
+        kpi++;
+    };
+
+    if (kpi < d.n_kp && d.kp_t[kpi] == 0) record(0);
+    for (int s = 0; s < T - 1; s++) {
+        UNR for (int i = 0; i < NU; i++) u[i] = AT(U, s * NU + i, b);
+        UNR for (int i = 0; i < NU; i++) cost_u += u[i] * d.R_diag[i] * u[i];
+        UNR for (int i = 0; i < NU; i++) {
+            const double ru = d.R_diag[i] * u[i];
+            UNR for (int q = 0; q < KWP; q++) gu[q] += PSI(s * NU + i, q) * ru;
+        }
+        StepAB<S> ab;
+        double xn[NX];
+        step_ab<S>(d, x, u, xn, ab);
+        UNR for (int i = 0; i < NX; i++) { xp[i] = x[i]; x[i] = xn[i]; }
+        const int i = s + 1;
+        if (kpi < d.n_kp && d.kp_t[kpi] == i) record(i);
+        if (i <= T - 2) {  // W_{i+1} = A_i W_i + B_i PSI_i
+            for (int q = 0; q < KWP; q++) {
+                if (S::ND == 2) { UNR for (int r = 0; r < DOF; r++) WL(r, q) += ab.dt * WL(DOF + r, q); }
+                UNR for (int r = 0; r < DOF; r++) {
+                    const double ps = PSI(i * NU + r, q);
+                    if (S::ND == 1) WL(r, q) += ab.dt * ps;
+                    else { WL(r, q) += ab.hdt2 * ps; WL(DOF + r, q) += ab.dt * ps; }
+                }
+                if (S::TM) {
+                    const double pl = PSI(i * NU + NU - 1, q);
+                    UNR for (int r = 0; r < NX; r++) WL(r, q) += ab.bc[r] * pl;
+                }
+            }
+        }
+    }
+    a.cost[b] = cost_e + cost_u + cost_l;  // cost0 of this iteration (BatchILQRCP.cpp:135)
+    UNR for (int q = 0; q < KWP; q++) AT(c.gu, q, b) = gu[q];
+#undef WL
+}
+
+template <class S, int KWP>
+__global__ __launch_bounds__(64) void k_cp_solve(Bufs a, CPArgs c) {
+    constexpr int NX = S::NX;
+    extern __shared__ double lds[];
+    const DevDesc& d = *a.desc;
+    const int lane = threadIdx.x, b = blockIdx.x * 64 + lane;
+    if (b >= d.B || !a.active[b]) return;
+    const int Bp = d.Bp;
+#define HL(r, q) lds[((r) * KWP + (q)) * 64 + lane]
+    double g[KWP];
+    UNR for (int q = 0; q < KWP; q++) g[q] = -AT(c.gu, q, b);
+    for (int r = 0; r < KWP; r++)
+        for (int q = 0; q < KWP; q++) HL(r, q) = c.H0[r * KWP + q];
+    for (int t = 0; t < d.n_kp; t++) {
+        const double* Ck = c.Ckp + (size_t)t * NX * NX * Bp;
+        const double* rk = c.rkp + (size_t)t * NX * Bp;
+        const double* Wk = c.Wkp + (size_t)t * NX * KWP * Bp;
+        for (int q = 0; q < KWP; q++) {
+            double wq[NX], cw[NX];  // column q of W_t and of C W_t
+            UNR for (int i = 0; i < NX; i++) wq[i] = AT(Wk, i * KWP + q, b);
+            UNR for (int i = 0; i < NX; i++) {
+                double s = 0;
+                UNR for (int j = 0; j < NX; j++) s += AT(Ck, i * NX + j, b) * wq[j];
+                cw[i] = s;
+            }
+            for (int r = 0; r < KWP; r++) {
+                double s = 0;
+                UNR for (int i = 0; i < NX; i++) s += AT(Wk, i * KWP + r, b) * cw[i];
+                HL(r, q) += s;
+            }
+            double s = 0;
+            UNR for (int i = 0; i < NX; i++) s += wq[i] * AT(rk, i, b);
+            g[q] += s;
+        }
+    }
+    // partial-pivot LU in place (Eigen PartialPivLU), rows of g permuted along
+    for (int k = 0; k < KWP; k++) {
+        int pr = k;
+        double best = fabs(HL(k, k));
+        for (int i = k + 1; i < KWP; i++) {
+            const double v = fabs(HL(i, k));
+            if (v > best) { best = v; pr = i; }
+        }
+        if (pr != k) {
+            for (int q = 0; q < KWP; q++) { const double t0 = HL(k, q); HL(k, q) = HL(pr, q); HL(pr, q) = t0; }
+        }
+        // g lives in registers: swap by select over the unrolled index
+        {
+            double gk = 0, gp = 0;
+            UNR for (int q = 0; q < KWP; q++) { if (q == k) gk = g[q]; if (q == pr) gp = g[q]; }
+            UNR for (int q = 0; q < KWP; q++) { if (q == k) g[q] = gp; else if (q == pr) g[q] = gk; }
+        }
+        const double pv = HL(k, k);
+        for (int i = k + 1; i < KWP; i++) {
+            const double fct = HL(i, k) / pv;
+            HL(i, k) = fct;
+            for (int q = k + 1; q < KWP; q++) HL(i, q) -= fct * HL(k, q);
+        }
+    }
+    // L y = P g ; U dw = y
+    UNR for (int i = 0; i < KWP; i++) {
+        double s = g[i];
+        UNR for (int j = 0; j < KWP; j++) if (j < i) s -= HL(i, j) * g[j];
+        g[i] = s;
+    }
+    UNR for (int i = KWP - 1; i >= 0; i--) {
+        double s = g[i];
+        UNR for (int j = 0; j < KWP; j++) if (j > i) s -= HL(i, j) * g[j];
+        g[i] = s / HL(i, i);
+    }
+    UNR for (int q = 0; q < KWP; q++) AT(c.dw, q, b) = g[q];
+#undef HL
+}
+
+template <class S, int KWP>
+__global__ __launch_bounds__(64) void k_cp_linesearch(Bufs a, CPArgs c) {
+    constexpr int NX = S::NX, NU = S::NU;
+    const DevDesc& d = *a.desc;
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= d.B || !a.active[b]) return;
+    const int Bp = d.Bp, T = d.T;
+    double dw[KWP];
+    UNR for (int q = 0; q < KWP; q++) dw[q] = AT(c.dw, q, b);
+    double* U = a.U[0];
+    const double cost0 = a.cost[b];
+    double alpha = 1.0, cost = 0, dun2 = 0;
+    bool first = true;
+    while (true) {  // BatchILQRCP.cpp:138-158
+        double x[NX], xp[NX], u[NU], xn[NX];
+        init_state<S>(d, a, b, x);
+        double cost_e = 0, cost_u = 0, cost_l = 0;
+        int kpi = 0;
+        auto kp_here = [&](int i) {
+            double tg[S::NF];
+            UNR for (int r = 0; r < S::NF; r++) tg[r] = AT(a.kp_tg, kpi * S::NF + r, b);
+            cost_e += kp_cost<S>(d, kpi, tg, x, nullptr);
+            if (i > 0) {
+                double Ld[NX], ql[NX];
+                limit_terms<S>(d, xp, Ld, ql);
+                UNR for (int r = 0; r < NX; r++) cost_l += ql[r] * Ld[r] * ql[r];
+            }
+            kpi++;
+        };
+        if (kpi < d.n_kp && d.kp_t[kpi] == 0) kp_here(0);
+        for (int s = 0; s < T - 1; s++) {
+            UNR for (int i = 0; i < NU; i++) {
+                double du = 0;
+                UNR for (int q = 0; q < KWP; q++) du += PSI(s * NU + i, q) * dw[q];
+                if (first) dun2 += du * du;
+                u[i] = AT(U, s * NU + i, b) + alpha * du;
+                cost_u += u[i] * d.R_diag[i] * u[i];
+            }
+            dyn_step<S>(d, x, u, xn);
+            UNR for (int i = 0; i < NX; i++) { xp[i] = x[i]; x[i] = xn[i]; }
+            if (kpi < d.n_kp && d.kp_t[kpi] == s + 1) kp_here(s + 1);
+        }
+        first = false;
+        cost = cost_e + cost_u + cost_l;
+        if ((cost < cost0) || (alpha < 1e-3)) break;
+        alpha /= 2;
+    }
+    for (int s = 0; s < T - 1; s++) {  // u = utmp
+        UNR for (int i = 0; i < NU; i++) {
+            double du = 0;
+            UNR for (int q = 0; q < KWP; q++) du += PSI(s * NU + i, q) * dw[q];
+            AT(U, s * NU + i, b) += alpha * du;
+        }
+    }
+    a.alpha[b] = alpha;
+    a.iters[b] = c.it + 1;
+    a.status[b] = (isfinite(cost) ? 0 : 1) | ((alpha < 1e-3) ? 2 : 0);
+    if (a.cost_trace) {
+        a.cost_trace[(size_t)c.it * Bp + b] = cost0;  // the reference prints the PRE-step cost (BatchILQRCP.cpp:160)
+        a.alpha_trace[(size_t)c.it * Bp + b] = alpha;
+    }
+    a.cost[b] = cost;
+    if (c.early_stop && alpha * sqrt(dun2) < 1e-3) a.active[b] = 0;  // :167
+}
+
+// controls <- U0, solver state reset
+template <class S>
+__global__ void k_cp_init(Bufs a) {
+    const DevDesc& d = *a.desc;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= d.B) return;
+    const int Bp = d.Bp;
+    for (int r = 0; r < (d.T - 1) * S::NU; r++) AT(a.U[0], r, b) = AT(a.U0, r, b);
+    a.cur[b] = 0;
+    a.active[b] = 1;
+    a.iters[b] = 0;
+    a.status[b] = 0;
+    a.alpha[b] = 1.0;
+    a.pend[b] = 0;
+    a.pred[b] = 0;
+}
+
+// final rollout of the solution so that X (and the cost of the returned u) can be read back
+template <class S>
+__global__ __launch_bounds__(64) void k_cp_final(Bufs a) {
+    constexpr int NX = S::NX, NU = S::NU;
+    const DevDesc& d = *a.desc;
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= d.B) return;
+    const int Bp = d.Bp, T = d.T;
+    double x[NX], u[NU], xn[NX];
+    init_state<S>(d, a, b, x);
+    for (int s = 0; s < T - 1; s++) {
+        UNR for (int i = 0; i < NX; i++) AT(a.X[0], s * NX + i, b) = x[i];
+        UNR for (int i = 0; i < NU; i++) u[i] = AT(a.U[0], s * NU + i, b);
+        dyn_step<S>(d, x, u, xn);
+        UNR for (int i = 0; i < NX; i++) x[i] = xn[i];
+    }
+    UNR for (int i = 0; i < NX; i++) AT(a.X[0], (T - 1) * NX + i, b) = x[i];
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+
+template <class T>
+static bool cp_alloc(BatchCPState& st, T** p, size_t n, hipStream_t s) {
+    void* q = nullptr;
+    if (hipMalloc(&q, (n ? n : 1) * sizeof(T)) != hipSuccess) return false;
+    st.allocs.push_back(q);
+    (void)hipMemsetAsync(q, 0, (n ? n : 1) * sizeof(T), s);
+    *p = (T*)q;
+    return true;
+}
+
 void batchcp_free(BatchCPState& st) {
-    if (st.psi) (void)hipFree(st.psi);
-    if (st.work) (void)hipFree(st.work);
+    for (void* q : st.allocs) (void)hipFree(q);
     st = BatchCPState();
+}
+
+template <class S, int KWP>
+static int run_cp(BatchCPState& st, const DevDesc& h, Bufs& bufs, int nb_iter, int early_stop, hipStream_t stream, std::string& err) {
+    constexpr int NX = S::NX;
+    const int B = h.B;
+    const dim3 grid((B + 63) / 64), block(64);
+    const size_t lds_w = sizeof(double) * NX * KWP * 64, lds_h = sizeof(double) * KWP * KWP * 64;
+    if (lds_w > 160 * 1024 || lds_h > 160 * 1024) { err = "ilqr_solve_batch_cp: basis too wide for the LDS tiles (n_x * Kw <= 320, Kw <= 16)"; return 1; }
+    if (hipFuncSetAttribute((const void*)k_cp_linearize<S, KWP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_cp_solve<S, KWP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h) != hipSuccess) {
+        err = "ilqr_solve_batch_cp: cannot reserve LDS";
+        return 1;
+    }
+    CPArgs c;
+    c.psi = st.psi; c.H0 = st.H0; c.Wkp = st.Wkp; c.Ckp = st.Ckp; c.rkp = st.rkp; c.gu = st.gu; c.dw = st.dw; c.dun = st.dun;
+    c.Kw = st.Kw; c.early_stop = early_stop; c.n_alpha = 11; c.it = 0;
+    hipLaunchKernelGGL((k_cp_init<S>), dim3((B + 255) / 256), dim3(256), 0, stream, bufs);
+    for (int it = 0; it < nb_iter; it++) {
+        c.it = it;
+        hipLaunchKernelGGL((k_cp_linearize<S, KWP>), grid, block, lds_w, stream, bufs, c);
+        hipLaunchKernelGGL((k_cp_solve<S, KWP>), grid, block, lds_h, stream, bufs, c);
+        hipLaunchKernelGGL((k_cp_linesearch<S, KWP>), grid, block, 0, stream, bufs, c);
+    }
+    hipLaunchKernelGGL((k_cp_final<S>), grid, block, 0, stream, bufs);
+    if (hipGetLastError() != hipSuccess) { err = "ilqr_solve_batch_cp: kernel launch failed"; return 1; }
+    return 0;
+}
+
+int batchcp_solve(BatchCPState& st, const DevDesc& h, Bufs& bufs, int nx, int nu, int nf, int nq, const double* psi_host, int Kw,
+                  int nb_iter, int early_stop, hipStream_t stream, std::string& err) {
+    (void)nf; (void)nq;
+    if (!psi_host || Kw <= 0) { err = "ilqr_solve_batch_cp: null PSI / Kw <= 0"; return 1; }
+    if (Kw > 16) { err = "ilqr_solve_batch_cp: Kw > 16 not supported on the device yet"; return 1; }
+    if (nb_iter < 0) { err = "nb_iter < 0"; return 1; }
+    const int KWP = 16, T = h.T, Bp = h.Bp, nkp = h.n_kp > 0 ? h.n_kp : 1;
+    const int rows = (T - 1) * nu;
+    if (st.KWP != KWP || st.nkp != nkp || st.nx != nx || st.Bp != Bp || st.rows != rows) {
+        batchcp_free(st);
+        bool ok = cp_alloc(st, &st.psi, (size_t)rows * KWP, stream) && cp_alloc(st, &st.H0, (size_t)KWP * KWP, stream) &&
+                  cp_alloc(st, &st.Wkp, (size_t)nkp * nx * KWP * Bp, stream) && cp_alloc(st, &st.Ckp, (size_t)nkp * nx * nx * Bp, stream) &&
+                  cp_alloc(st, &st.rkp, (size_t)nkp * nx * Bp, stream) && cp_alloc(st, &st.gu, (size_t)KWP * Bp, stream) &&
+                  cp_alloc(st, &st.dw, (size_t)KWP * Bp, stream) && cp_alloc(st, &st.dun, (size_t)Bp, stream);
+        if (!ok) { batchcp_free(st); err = "ilqr_solve_batch_cp: hipMalloc failed"; return 1; }
+        st.KWP = KWP; st.nkp = nkp; st.nx = nx; st.Bp = Bp; st.rows = rows;
+    }
+    st.Kw = Kw;
+    // PSI padded to KWP columns; H0 = PSI' R PSI with 1 on the padded diagonal (keeps H non-singular, dw_pad = 0)
+    std::vector<double> psip((size_t)rows * KWP, 0.0), H0((size_t)KWP * KWP, 0.0);
+    for (int k = 0; k < rows; k++)
+        for (int q = 0; q < Kw; q++) psip[(size_t)k * KWP + q] = psi_host[(size_t)k * Kw + q];
+    for (int a_ = 0; a_ < Kw; a_++)
+        for (int b_ = 0; b_ < Kw; b_++) {
+            double s = 0;
+            for (int k = 0; k < rows; k++) s += psi_host[(size_t)k * Kw + a_] * h.R_diag[k % nu] * psi_host[(size_t)k * Kw + b_];
+            H0[(size_t)a_ * KWP + b_] = s;
+        }
+    for (int q = Kw; q < KWP; q++) H0[(size_t)q * KWP + q] = 1.0;
+    if (hipMemcpyAsync(st.psi, psip.data(), psip.size() * sizeof(double), hipMemcpyHostToDevice, stream) != hipSuccess ||
+        hipMemcpyAsync(st.H0, H0.data(), H0.size() * sizeof(double), hipMemcpyHostToDevice, stream) != hipSuccess ||
+        hipStreamSynchronize(stream) != hipSuccess) {
+        err = "ilqr_solve_batch_cp: PSI upload failed";
+        return 1;
+    }
+    if (h.kind == 0 && h.nd == 1) return run_cp<Sys<0, 1>, 16>(st, h, bufs, nb_iter, early_stop, stream, err);
+    if (h.kind == 0 && h.nd == 2) return run_cp<Sys<0, 2>, 16>(st, h, bufs, nb_iter, early_stop, stream, err);
+    if (h.kind == 1 && h.nd == 1) return run_cp<Sys<1, 1>, 16>(st, h, bufs, nb_iter, early_stop, stream, err);
+    return run_cp<Sys<1, 2>, 16>(st, h, bufs, nb_iter, early_stop, stream, err);
 }
 
 }  // namespace ilqr

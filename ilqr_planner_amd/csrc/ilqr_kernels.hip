@@ -60,6 +60,7 @@ __global__ __launch_bounds__(64) void k_init_rollout(Bufs a, double penalty) {
     a.active[b] = 1;
     a.iters[b] = 0;
     a.pend[b] = 0;
+    a.pred[b] = 0;
     a.status[b] = isfinite(cost) ? 0 : 1;
 }
 

@@ -24,7 +24,8 @@ struct Bufs {
     int* iters;
     int* status;
     double* kpd;    // [n_kp][NX + NX*NX][Bp] l_x | l_xx of the keypoint steps of the current trajectory (k_kp_derivs)
-    int* pend;      // [Bp] line-search winner index still to be applied by the APPLY pass (0 = nothing pending)
+    int* pend;      // [Bp] line-search winner index + 1 still to be applied by the APPLY pass (0 = nothing pending)
+    int* pred;      // [Bp] predicted winner index of the next line search (= winner of the previous iteration)
     double* cost_trace;   // [nb_iter][Bp] or null
     double* alpha_trace;  // [nb_iter][Bp] or null
     // augmented Lagrangian (shared constraint rows, per-instance multipliers)

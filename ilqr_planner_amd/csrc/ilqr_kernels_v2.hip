@@ -26,6 +26,8 @@
 //                  five dense products of the generic sweep (ilqr_kernels.hip k_backward), all in registers.
 // Everything a loop needs from the shared descriptor is copied into registers before the loop: the compiler cannot
 // prove that the trajectory stores do not alias the descriptor and would otherwise re-issue scalar loads every step.
+#include <cstdlib>
+
 #include "ilqr_kernels.hpp"
 #include "ilqr_step.hpp"
 
@@ -81,19 +83,25 @@ __global__ __launch_bounds__(256) void k_forward_tile(Bufs a, FwdArgs f) {
     const int b0 = blockIdx.x * 16, b = b0 + il;
     const int Bp = d.Bp, T = d.T, B = d.B;
 
-    bool part;
+    // SPEC: lane `ai` tries alpha = 2^-ai; the lane whose index equals the instance's PREDICTED winner (the winner of
+    // its previous iteration: alpha = 1 early on, the alpha floor once converged) writes its trajectory speculatively.
+    // APPLY: lane 0 re-rolls the actual winner (pend = winner + 1) when the prediction was wrong.
+    bool part, writer;
     double alpha;
     if (!APPLY) {
         part = (b < B) && a.active[b] && (ai < f.n_alpha);
         alpha = ldexp(1.0, -ai);
+        const int pr = (b < B) ? a.pred[b] : 0;
+        writer = part && (ai == (pr < f.n_alpha ? pr : f.n_alpha - 1));
     } else {
         const int w = (b < B) ? a.pend[b] : 0;
         part = (w > 0) && (ai == 0);
-        alpha = ldexp(1.0, -w);
+        alpha = ldexp(1.0, -(w - 1));
+        writer = part;
     }
     if (!__syncthreads_or(part ? 1 : 0)) return;  // nothing to do for these 16 instances (uniform)
-    const bool writer = part && (ai == 0);
-    if (ai == 0) s_wr[il] = writer ? 1 : 0;
+    if (writer) s_wr[il] = 1;
+    else if (ai == 0 && !(part && !APPLY)) s_wr[il] = 0;  // instance without any writer lane
 
     // descriptor -> registers
     LimRegs<NX> lim;
@@ -243,8 +251,9 @@ __global__ __launch_bounds__(256) void k_forward_tile(Bufs a, FwdArgs f) {
     const int w = grp ? (__ffs((int)grp) - 1) : (f.n_alpha - 1);
     const double wcost = __shfl(newCost, g0 + w);
     const double wdun = __shfl(dun, g0 + w);
-    if (writer) {  // lane 0 of an active instance
+    if (part && ai == 0) {  // bookkeeping by lane 0 of every active instance
         const double walpha = ldexp(1.0, -w);
+        const int pr = a.pred[b] < f.n_alpha ? a.pred[b] : f.n_alpha - 1;
         a.cost[b] = wcost;
         a.alpha[b] = walpha;
         a.iters[b] = f.it + 1;
@@ -253,8 +262,9 @@ __global__ __launch_bounds__(256) void k_forward_tile(Bufs a, FwdArgs f) {
             a.cost_trace[(size_t)f.it * Bp + b] = wcost;
             a.alpha_trace[(size_t)f.it * Bp + b] = walpha;
         }
-        if (w == 0) a.cur[b] = 1 - a.cur[b];  // the speculatively written alpha = 1 trajectory is the accepted one
-        else a.pend[b] = w;
+        if (w == pr) a.cur[b] = 1 - a.cur[b];  // the speculatively written trajectory is the accepted one
+        else a.pend[b] = w + 1;
+        a.pred[b] = w;
         bool stop = f.early_stop && (walpha * sqrt(wdun) < d.stop_tol);
         if (!f.al) stop = stop && (wcost < 1e-3);  // ILQRRecursive.cpp:174 vs AL-ILQR.cpp:225
         if (stop) a.active[b] = 0;
@@ -323,7 +333,7 @@ __global__ __launch_bounds__(64) void k_backward_si(Bufs a) {
     constexpr int N = 7, NS = N * (N + 1) / 2;
     constexpr int MRR = MR > 0 ? MR : 1;
     const DevDesc& d = *a.desc;
-    const int b = blockIdx.x * 64 + threadIdx.x;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= d.B) return;
     if (!a.active[b]) return;
     const int Bp = d.Bp, T = d.T;
@@ -544,7 +554,8 @@ bool backward_si_supported(int kind, int nd, bool al, int m, int per_step, bool 
 
 void launch_solver_v2(int kind, int nd, int which, bool al, const Bufs& a, int B, int T, hipStream_t st, const FwdArgs& f) {
     if (which == KER_BACKWARD_SI) {
-        const dim3 grid((B + 63) / 64), block(64);
+        static const int bs = std::getenv("ILQR_BWD_BLOCK") ? std::atoi(std::getenv("ILQR_BWD_BLOCK")) : 64;  // lanes used per wave (experiment)
+        const dim3 grid((B + bs - 1) / bs), block(bs);
         if (!al) hipLaunchKernelGGL((k_backward_si<0>), grid, block, 0, st, a);
         else if (a.m <= 1) hipLaunchKernelGGL((k_backward_si<1>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((k_backward_si<4>), grid, block, 0, st, a);

@@ -27,7 +27,7 @@ ILQR_DEV double con_g(const Bufs& a, int k, int r, const double* x, const double
 }
 
 // lx, lxx of a stage (System::cost_x / cost_xx, System.cpp:248-308).  P <- lxx, p <- lx.
-template <class S>
+template <class S, bool WITH_LIMITS = true>
 ILQR_DEV void stage_derivs(const DevDesc& d, const Bufs& a, int b, const double* x, int kpi, double (*lxx)[S::NX], double* lx) {
     constexpr int NX = S::NX, NQ = S::NQ, NF = S::NF;
     const int Bp = d.Bp;
@@ -85,7 +85,7 @@ ILQR_DEV void stage_derivs(const DevDesc& d, const Bufs& a, int b, const double*
             lxx[NX - 1][NX - 1] += Q[(NQ - 1) * NQ + NQ - 1];
         }
     }
-    if (d.limits_set) {
+    if (WITH_LIMITS && d.limits_set) {
         UNR for (int i = 0; i < NX; i++) {
             if (d.lw[i] != 0) {
                 double qv = 0, L = 0;

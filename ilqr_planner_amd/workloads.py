@@ -38,6 +38,9 @@ def config(name: str):
                    ctimes=[2.5, 5.0], solver="recursive", nb_iter=20),
         "C5": dict(kind=capi.SYS_POS_ORN, nb_deriv=1, T=400, dt=0.01, B=8192, seed=4, Qdiag=[P, P], solver="batch_cp", nb_iter=10,
                    psi=dict(kind="unitstep", K=2)),
+        # Batch-CP on the time-augmented 2nd-order system (the C4 system shape), sawtooth x controls + unit-step x sqrt(dt)
+        "C4cp": dict(kind=capi.SYS_POS_ORN_TIME, nb_deriv=2, T=50, dt=None, B=64, seed=5, Qdiag=[P + V + [.1], P + V + [.1]],
+                     ctimes=[2.5, 5.0], solver="batch_cp", nb_iter=8, psi=dict(kind="sawtooth+unitstep_dt", K=2)),
     }
     return dict(cfgs[name])
 

@@ -1,0 +1,77 @@
+"""GPU parity of the Batch-CP solver (BatchILQRCP) through the C ABI."""
+import numpy as np
+import pytest
+
+from tests.helpers import assert_trace, golden, oracle_system_of_instance, orc, psi_of
+from tests.test_gpu_parity import _tutorial_problem
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from ilqr_planner_amd import capi
+
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+CP = [(n, i) for n, c in golden()["cases"].items() for i, s in enumerate(c["solves"]) if s["solver"] == "BatchILQRCP"]
+
+
+@pytest.mark.parametrize("name,idx", CP, ids=[n for n, _ in CP])
+def test_tutorial_cp_traces_on_gpu(ctx, name, idx):
+    """The four control-primitive traces of the reference's notebooks (unit-step, sawtooth and mixed bases; 1st/2nd
+    order; with and without the time state) reproduced on the GPU: printed pre-step cost to 6 significant digits,
+    identical alpha sequence and iteration count (early stop)."""
+    case = golden()["cases"][name]
+    sv = case["solves"][idx]
+    B = 3
+    p = _tutorial_problem(ctx, case, B)
+    psi = psi_of(sv["psi"], p.T, p.dims.n_u)
+    p.solve_batch_cp(psi, sv["nb_iter"], sv["early_stop"])
+    iters = p.iters()
+    ct, at = p.trace(sv["nb_iter"])
+    nref = len(sv["trace"])
+    for b in range(B):
+        assert iters[b] == nref
+        assert_trace(ct[b, :nref], at[b, :nref], sv["trace"])
+    p.close()
+
+
+@pytest.mark.parametrize("cfg_name,B,nb_iter", [("C5", 48, 6), ("C4cp", 24, 5)])
+def test_cp_random_batch_vs_oracle(ctx, cfg_name, B, nb_iter):
+    from ilqr_planner_amd import workloads
+
+    cfg = workloads.config(cfg_name)
+    desc, inp = workloads.make_batch(ctx, cfg, B=B)
+    p = workloads.load_batch(ctx, desc, inp, B)
+    psi = psi_of(cfg["psi"], cfg["T"], p.dims.n_u)
+    p.solve_batch_cp(psi, nb_iter, False)
+    U = p.U()
+    ct, at = p.trace(nb_iter)
+    bad = 0
+    for i in range(B):
+        s = oracle_system_of_instance(cfg, inp, i)
+        r = orc.solve_batch_cp(s, psi, inp["U0"][i].reshape(-1), nb_iter, False)
+        same = np.array_equal(at[i], r["trace_alpha"])
+        rel = np.abs(ct[i] - r["trace_cost"]) / np.maximum(np.abs(r["trace_cost"]), 1e-12)
+        if same:
+            assert rel.max() <= 1e-4, f"instance {i}: cost trace rel err {rel.max():.2e}"
+            np.testing.assert_allclose(U[i].reshape(-1), r["u"], rtol=0, atol=1e-4 * max(1.0, np.abs(r["u"]).max()))
+        else:
+            bad += 1
+    assert bad <= max(1, B // 10), f"{bad} of {B} instances took a different alpha path"
+    p.close()
+
+
+def test_cp_errors(ctx):
+    from ilqr_planner_amd import workloads
+
+    cfg = workloads.config("C5")
+    desc, inp = workloads.make_batch(ctx, cfg, B=4)
+    p = workloads.load_batch(ctx, desc, inp, 4)
+    with pytest.raises(RuntimeError, match="Kw > 16"):
+        p.solve_batch_cp(np.zeros(((cfg["T"] - 1) * 7, 28)), 1, False)
+    p.close()
