@@ -38,6 +38,10 @@ def config(name: str):
                    ctimes=[2.5, 5.0], solver="recursive", nb_iter=20),
         "C5": dict(kind=capi.SYS_POS_ORN, nb_deriv=1, T=400, dt=0.01, B=8192, seed=4, Qdiag=[P, P], solver="batch_cp", nb_iter=10,
                    psi=dict(kind="unitstep", K=2)),
+        # 2nd-order PosOrn (state [q, dq], control ddq) and 1st-order time system: the remaining System shapes of SURVEY.md 8
+        "C2nd": dict(kind=capi.SYS_POS_ORN, nb_deriv=2, T=100, dt=0.05, B=256, seed=6, Qdiag=[P + [1, 1, 1, 0, 0, 0], P + V], solver="recursive", nb_iter=12),
+        "C4t1": dict(kind=capi.SYS_POS_ORN_TIME, nb_deriv=1, T=100, dt=None, B=256, seed=7, Qdiag=[P + [0], P + [.1]], ctimes=[2.0, 5.0],
+                     solver="recursive", nb_iter=14),
         # Batch-CP on the time-augmented 2nd-order system (the C4 system shape), sawtooth x controls + unit-step x sqrt(dt)
         "C4cp": dict(kind=capi.SYS_POS_ORN_TIME, nb_deriv=2, T=50, dt=None, B=64, seed=5, Qdiag=[P + V + [.1], P + V + [.1]],
                      ctimes=[2.5, 5.0], solver="batch_cp", nb_iter=8, psi=dict(kind="sawtooth+unitstep_dt", K=2)),
