@@ -1,0 +1,781 @@
+// ilqr_host.cpp -- implementation of the host mirror (see ilqr_host.hpp).  Plumbing only: state, lowering, C-ABI calls.
+#include "ilqr_host.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <functional>
+#include <iostream>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+
+namespace ilqr_planner {
+
+// ------------------------------------------------------------------------------------------------ device context
+
+static ilqr_ctx* g_ctx = nullptr;
+
+ilqr_ctx* device_context() {
+    if (!g_ctx) {
+        int dev = 0;
+        if (const char* e = std::getenv("LOCAL_RANK")) dev = std::atoi(e);
+        if (const char* e = std::getenv("ILQR_DEVICE")) dev = std::atoi(e);
+        const int rc = ilqr_ctx_create(dev, &g_ctx);
+        if (rc) {
+            g_ctx = nullptr;
+            throw std::runtime_error("[ilqr_hip] no usable MI355X/HIP device " + std::to_string(dev) + " (ilqr_ctx_create code " + std::to_string(rc) +
+                                     "); the solvers and the kinematics only run on the GPU");
+        }
+    }
+    return g_ctx;
+}
+
+void check(int rc) {
+    if (rc) throw std::runtime_error(ilqr_last_error(g_ctx));
+}
+
+// ------------------------------------------------------------------------------------------------ Sd (utils/sd.h)
+
+static double vdot(const Vec& a, const Vec& b) {
+    double s = 0;
+    for (size_t i = 0; i < a.size(); i++) s += a[i] * b[i];
+    return s;
+}
+static double vnorm(const Vec& a) { return std::sqrt(vdot(a, a)); }
+static bool is_zero(const Vec& a) {  // Eigen isZero(1e-12)
+    for (double v : a)
+        if (!(std::fabs(v) <= 1e-12)) return false;
+    return true;
+}
+
+namespace Sd {
+Mat dQuatToDxJac(const Vec& q) {  // sd.h:23-27
+    Mat J(3, 4);
+    const double r[12] = {-q[1], q[0], -q[3], q[2], -q[2], q[3], q[0], -q[1], -q[3], -q[2], q[1], q[0]};
+    J.d.assign(r, r + 12);
+    return J;
+}
+Vec expMap(Vec base, const Vec& u) {  // sd.h:32-43
+    const double nb = vnorm(base);
+    for (auto& v : base) v /= nb;
+    const double nu = vnorm(u);
+    if (nu == 0) return base;
+    Vec r(base.size());
+    for (size_t i = 0; i < r.size(); i++) r[i] = base[i] * std::cos(nu) + u[i] / nu * std::sin(nu);
+    const double nr = vnorm(r);
+    for (auto& v : r) v /= nr;
+    return r;
+}
+double distance(const Vec& x, const Vec& y) {  // sd.h:48-62
+    double d = vdot(x, y);
+    if (d > 1) d = 1;
+    else if (d < -1) d = -1;
+    double ac = std::acos(d);
+    if (d < 0) ac -= M_PI;
+    return ac;
+}
+Vec logMap(Vec base, Vec y) {  // sd.h:67-82
+    if (is_zero(base) || is_zero(y)) return Vec(base.size(), 0.0);
+    const double nb = vnorm(base), ny = vnorm(y);
+    for (auto& v : base) v /= nb;
+    for (auto& v : y) v /= ny;
+    const double by = vdot(base, y);
+    Vec t(base.size());
+    for (size_t i = 0; i < t.size(); i++) t[i] = y[i] - by * base[i];
+    const double nt = vnorm(t);
+    if (nt == 0) return Vec(base.size(), 0.0);
+    const double d = distance(base, y);
+    for (auto& v : t) v = d * v / nt;
+    return t;
+}
+Vec transport(const Vec& v, const Vec& base1, const Vec& base2) {  // sd.h:87-99
+    if (is_zero(base1) || is_zero(base2)) return v;
+    const double dsq = std::pow(distance(base1, base2), 2);
+    if (dsq == 0) return v;
+    const Vec l12 = logMap(base1, base2), l21 = logMap(base2, base1);
+    const double f = vdot(l12, v) / dsq;
+    Vec o(v.size());
+    for (size_t i = 0; i < o.size(); i++) o[i] = v[i] - f * (l12[i] + l21[i]);
+    return o;
+}
+}  // namespace Sd
+
+// ------------------------------------------------------------------------------------------------ primitives (utils/primitives.cpp)
+
+static int binomial(int n, int k) { return (k == 0 || k == n) ? 1 : binomial(n - 1, k - 1) + binomial(n - 1, k); }
+
+Mat buildPsiRBF(int dim, int K) {
+    Mat psi(dim, K);
+    const double bw = ((double)dim) / K, sig = bw;
+    double avg = bw / 2;
+    for (int i = 0; i < K; i++) {
+        for (int j = 0; j < dim; j++) psi(j, i) = 1 / (2 * M_PI * sig) * std::exp(-1 * (j - avg) * (j - avg) / (2 * sig * sig));
+        avg += bw;
+    }
+    return psi;
+}
+Mat buildPsiBernstein(int dim, int K) {
+    Mat psi(dim, K);
+    const int order = K - 1;
+    for (int i = 0; i < K; i++) {
+        const int b = binomial(order, i);
+        for (int j = 0; j < dim; j++) {
+            const double t = ((double)j) / (dim - 1);
+            psi(j, i) = b * std::pow(t, i) * std::pow(1 - t, order - i);
+        }
+    }
+    return psi;
+}
+Mat buildPsiUnitstep(int dim, int K) {
+    Mat psi(dim, K);
+    const int bw = (int)std::round(((double)dim) / K);
+    int lo = 0, hi = bw;
+    for (int i = 0; i < K; i++) {
+        for (int j = 0; j < dim; j++) psi(j, i) = (j >= lo && j < hi) ? 1.0 / bw : 0;
+        lo += bw;
+        hi += bw;
+    }
+    return psi;
+}
+Mat buildPsiSawtooth(int dim, int K) {
+    Mat psi(dim, K);
+    const int bw = (int)std::ceil(((double)dim) / K);
+    double lo = 0, hi = bw;
+    for (int i = 0; i < K; i++) {
+        for (int j = 0; j < dim; j++) psi(j, i) = (j >= lo && j < hi) ? ((j - lo) / (bw - 1) - 0.5) : 0;
+        lo += bw;
+        hi += bw;
+    }
+    return psi;
+}
+Mat buildPsiLinear(int dim, int K) {
+    const Mat a = buildPsiUnitstep(dim, K), b = buildPsiSawtooth(dim, K);
+    Mat psi(dim, 2 * K);
+    for (int j = 0; j < dim; j++)
+        for (int i = 0; i < K; i++) {
+            psi(j, i) = a(j, i);
+            psi(j, K + i) = b(j, i);
+        }
+    return psi;
+}
+
+// ------------------------------------------------------------------------------------------------ sim
+
+namespace sim {
+Mat SimulationInterface::Jt() {
+    Mat j = J(), o(nbCarDim, j.cols);
+    for (int r = 0; r < nbCarDim; r++)
+        for (int c = 0; c < j.cols; c++) o(r, c) = j(r, c);
+    return o;
+}
+Mat SimulationInterface::Jr() {
+    Mat j = J(), o(nbCarDim, j.cols);
+    for (int r = 0; r < nbCarDim; r++)
+        for (int c = 0; c < j.cols; c++) o(r, c) = j(j.rows - nbCarDim + r, c);
+    return o;
+}
+void SimulationInterface::sendAcc(double dt, const Vec& a, bool updateKin) {  // SimulationInterface.cpp:19-26
+    for (int i = 0; i < dof; i++) {
+        q[i] += dt * dq[i] + dt * dt / 2 * a[i];
+        dq[i] += dt * a[i];
+    }
+    t += dt;
+    if (updateKin) updateKinematics();
+    ddq = a;
+}
+void SimulationInterface::sendVel(double dt, const Vec& v, bool updateKin) {  // :28-31
+    dq = v;
+    sendAcc(dt, Vec(v.size(), 0.0), updateKin);
+}
+Vec SimulationInterface::getEEAngVelQuat() {  // :69-73
+    const Mat H = Sd::dQuatToDxJac(getEEOrnQuat());
+    const Vec ww = getEEAngVel();
+    Vec o(4, 0.0);
+    for (int i = 0; i < 4; i++) o[i] = .5 * (H(0, i) * ww[0] + H(1, i) * ww[1] + H(2, i) * ww[2]);
+    return o;
+}
+void SimulationInterface::setConfiguration(const Vec& q_, const Vec& dq_, bool reset_time) {  // :91-98
+    q = q_;
+    dq = dq_;
+    updateKinematics();
+    if (reset_time) t = 0;
+}
+
+KDLRobot::KDLRobot(const std::string& urdf, const std::string& baseFrame, const std::string& tipFrame, const Vec& q_, const Vec& dq_,
+                   const Vec& transform_rpy, const Vec& transform_xyz, const bool& is_path) {
+    dof = (int)q_.size();
+    nbCarDim = 3;
+    q = q_;
+    dq = dq_;
+    ddq = Vec(dof, 0.0);
+    x = dx = w = Vec(3, 0.0);
+    ornQuat = Vec(4, 0.0);
+    Jac = Mat(6, dof);
+    std::string text = urdf;
+    if (is_path) {
+        std::ifstream f(urdf);
+        if (!f) throw std::runtime_error("[KDLRobot] Unable to open URDF file " + urdf);
+        std::stringstream ss;
+        ss << f.rdbuf();
+        text = ss.str();
+    }
+    if (transform_rpy.size() != 3 || transform_xyz.size() != 3) throw std::runtime_error("[KDLRobot] transform_rpy / transform_xyz must have 3 entries");
+    ilqr_desc_defaults(&chain_);
+    lower_.assign(ILQR_MAX_SEG, 0.0);
+    upper_.assign(ILQR_MAX_SEG, 0.0);
+    if (ilqr_chain_from_urdf(text.c_str(), baseFrame.c_str(), tipFrame.c_str(), transform_rpy.data(), transform_xyz.data(), &chain_, lower_.data(), upper_.data()))
+        throw std::runtime_error(ilqr_urdf_last_error());  // "[KDLRobot] Unable to build kinematic chain from <base> to <tip>"
+    if (chain_.dof != dof)
+        throw std::runtime_error("[KDLRobot] chain has " + std::to_string(chain_.dof) + " moving joints but q has " + std::to_string(dof) + " entries");
+    lower_.resize(dof);
+    upper_.resize(dof);
+    updateKinematics();
+}
+
+void KDLRobot::updateKinematics() {  // KDLRobot.cpp:83-115
+    ilqr_ctx* c = device_context();
+    std::vector<double> jac(6 * dof);
+    if (ilqr_fk_batch(c, &chain_, 1, q.data(), x.data(), ornQuat.data(), jac.data()))
+        throw std::runtime_error(std::string("[KinModel] Error while computing Jacobian and FK! ") + ilqr_last_error(c));
+    Jac = Mat(6, dof);
+    Jac.d = jac;
+    for (int i = 0; i < 3; i++) {
+        dx[i] = 0;
+        w[i] = 0;
+        for (int j = 0; j < dof; j++) {
+            dx[i] += Jac(i, j) * dq[j];
+            w[i] += Jac(3 + i, j) * dq[j];
+        }
+    }
+}
+
+bool KDLRobot::lowerChain(ilqr_problem_desc* d) const {
+    d->dof = chain_.dof;
+    d->n_seg = chain_.n_seg;
+    std::copy(std::begin(chain_.seg_joint), std::end(chain_.seg_joint), std::begin(d->seg_joint));
+    std::memcpy(d->seg_xyz, chain_.seg_xyz, sizeof(chain_.seg_xyz));
+    std::memcpy(d->seg_R, chain_.seg_R, sizeof(chain_.seg_R));
+    std::memcpy(d->seg_axis, chain_.seg_axis, sizeof(chain_.seg_axis));
+    return true;
+}
+}  // namespace sim
+
+// ------------------------------------------------------------------------------------------------ keypoints
+
+namespace sys {
+PosOrnKeypoint::PosOrnKeypoint(const Vec& position, const Vec& orientation, const Mat& precision, const int& timestep)
+    : Keypoint(timestep, KpType::FIRST_ORDER, "POS_ORN"), position_(position), orientation_(orientation), precision_(precision), state_size_(7) {}
+PosOrnKeypoint::PosOrnKeypoint(const Vec& position, const Vec& dposition, const Vec& orientation, const Vec& dorientation, const Mat& precision,
+                               const int& timestep)
+    : Keypoint(timestep, KpType::SECOND_ORDER, "POS_ORN"), position_(position), orientation_(orientation), dposition_(dposition),
+      dorientation_(dorientation), precision_(precision), state_size_(14) {}
+
+static void append(Vec& o, const Vec& a) { o.insert(o.end(), a.begin(), a.end()); }
+
+Vec PosOrnKeypoint::getState() const {  // PosOrnKeypoint.cpp:12-22 (2nd order: [p, dp, quat, dquat] -- the reference's own layout)
+    Vec s;
+    append(s, position_);
+    if (type_ == KpType::SECOND_ORDER) append(s, dposition_);
+    append(s, orientation_);
+    if (type_ == KpType::SECOND_ORDER) append(s, dorientation_);
+    return s;
+}
+Vec PosOrnKeypoint::targetFx() const {
+    Vec s;
+    append(s, position_);
+    append(s, orientation_);
+    if (type_ == KpType::SECOND_ORDER) { append(s, dposition_); append(s, dorientation_); }
+    return s;
+}
+Vec PosOrnKeypoint::diff(const Vec& state) const {  // PosOrnKeypoint.cpp:24-45
+    const int rs = state_size_ - type_;
+    Vec res(rs, 0.0);
+    if (!is_zero(state)) {
+        const Mat H = Sd::dQuatToDxJac(orientation_);
+        for (int i = 0; i < 3; i++) res[i] = position_[i] - state[i];
+        const Vec lm = Sd::logMap(orientation_, Vec(state.begin() + 3, state.begin() + 7));
+        for (int i = 0; i < 3; i++) res[3 + i] = -2 * (H(i, 0) * lm[0] + H(i, 1) * lm[1] + H(i, 2) * lm[2] + H(i, 3) * lm[3]);
+        if (type_ == KpType::SECOND_ORDER) {
+            for (int i = 0; i < 3; i++) res[6 + i] = dposition_[i] - state[7 + i];
+            const Vec tr = Sd::transport(Vec(state.begin() + 10, state.begin() + 14), Vec(state.begin() + 3, state.begin() + 7), orientation_);
+            Vec dv(4);
+            for (int i = 0; i < 4; i++) dv[i] = dorientation_[i] - tr[i];
+            for (int i = 0; i < 3; i++) res[9 + i] = -2 * (H(i, 0) * dv[0] + H(i, 1) * dv[1] + H(i, 2) * dv[2] + H(i, 3) * dv[3]);
+        }
+    }
+    return res;
+}
+
+SpacetimeKeypoint::SpacetimeKeypoint(const Vec& position, const Vec& orientation, const Mat& precision, const double& continuous_time, const int& timestep)
+    : PosOrnKeypoint(position, orientation, precision, timestep), continuous_time_(continuous_time) { TAG_ = "POS_ORN_TIME"; }
+SpacetimeKeypoint::SpacetimeKeypoint(const Vec& position, const Vec& dposition, const Vec& orientation, const Vec& dorientation, const Mat& precision,
+                                     const double& continuous_time, const int& timestep)
+    : PosOrnKeypoint(position, dposition, orientation, dorientation, precision, timestep), continuous_time_(continuous_time) { TAG_ = "POS_ORN_TIME"; }
+Vec SpacetimeKeypoint::getState() const {  // SpacetimeKeypoint.cpp:12-17
+    Vec s = PosOrnKeypoint::getState();
+    s.push_back(continuous_time_);
+    return s;
+}
+Vec SpacetimeKeypoint::targetFx() const {
+    Vec s = PosOrnKeypoint::targetFx();
+    s.push_back(continuous_time_);
+    return s;
+}
+Vec SpacetimeKeypoint::diff(const Vec& state) const {  // :19-25
+    Vec r = PosOrnKeypoint::diff(Vec(state.begin(), state.end() - 1));
+    r.push_back(continuous_time_ - state.back());
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------ systems
+
+System::System(const std::shared_ptr<sim::SimulationInterface>& r_, const std::vector<std::shared_ptr<Keypoint>>& kps, const Vec& RtDiag, const Vec& qMax,
+               const Vec& qMin, const Vec& dqMax, const Vec& dqMin, int horizon, int nb_deriv, const std::vector<std::string>& tags)
+    : r(r_), keypoints(kps), Rdiag(RtDiag), horizon_(horizon), nb_deriv_(nb_deriv), EXPECTED_KP_TAGS_(tags) {  // System.cpp:28-61
+    limits_set_ = true;
+    penalty_ = 1;
+    init();
+    const int dof = r->getDOF();
+    const int n = nb_deriv_ * dof;
+    state_max_.assign(n, 0.0);
+    state_min_.assign(n, 0.0);
+    joint_limits_weight_.assign(n, 1);
+    if ((int)qMax.size() != dof || (int)qMin.size() != dof) throw std::runtime_error("[System] qMax/qMin must have one entry per joint");
+    if (nb_deriv_ == 1) {
+        state_max_ = qMax;
+        state_min_ = qMin;
+    } else if (nb_deriv_ == 2) {
+        Vec dM = dqMax.empty() ? Vec(dof, 0.0) : dqMax, dm = dqMin.empty() ? Vec(dof, 0.0) : dqMin;
+        for (int i = 0; i < dof; i++) {
+            state_max_[i] = qMax[i]; state_min_[i] = qMin[i];
+            state_max_[dof + i] = dM[i]; state_min_[dof + i] = dm[i];
+        }
+        double diff2 = 0, n1 = 0, n2 = 0;  // Eigen isApprox (System.cpp:58-60)
+        for (int i = 0; i < dof; i++) { diff2 += (dM[i] - dm[i]) * (dM[i] - dm[i]); n1 += dM[i] * dM[i]; n2 += dm[i] * dm[i]; }
+        if (diff2 <= 1e-24 * std::min(n1, n2))
+            for (int i = 0; i < dof; i++) joint_limits_weight_[dof + i] = 0;
+    }
+}
+
+System::System(const std::shared_ptr<sim::SimulationInterface>& r_, const std::vector<std::shared_ptr<Keypoint>>& kps, const Vec& RtDiag, int horizon,
+               int nb_deriv, const std::vector<std::string>& tags)
+    : r(r_), keypoints(kps), Rdiag(RtDiag), horizon_(horizon), nb_deriv_(nb_deriv), EXPECTED_KP_TAGS_(tags) {  // System.cpp:63-75
+    limits_set_ = false;
+    penalty_ = 0;
+    init();
+}
+
+void System::init() {  // System.cpp:77-86
+    std::stable_sort(keypoints.begin(), keypoints.end(),
+                     [](const std::shared_ptr<Keypoint>& a, const std::shared_ptr<Keypoint>& b) { return a->getTimestep() < b->getTimestep(); });
+    if (!EXPECTED_KP_TAGS_.empty()) checkKeypoints();
+}
+
+void System::checkKeypoints() {  // System.cpp:363-372
+    for (auto& kp : keypoints) {
+        if (std::find(EXPECTED_KP_TAGS_.begin(), EXPECTED_KP_TAGS_.end(), kp->getTAG()) == EXPECTED_KP_TAGS_.end())
+            throw std::runtime_error("[PosOrnPlannerSys] Wrong keypoint type: got " + kp->getTAG());
+        if (kp->getType() != nb_deriv_)
+            throw std::runtime_error("[PosOrnPlannerSys] Wrong keypoint order (nb_deriv_): Expecting " + std::to_string(nb_deriv_) + " got " +
+                                     std::to_string(kp->getType()));
+    }
+}
+
+std::vector<int> System::getKpIndexes() {
+    std::vector<int> v;
+    for (auto& kp : keypoints) v.push_back(kp->getTimestep());
+    return v;
+}
+
+Mat System::getRt() {
+    Mat R((int)Rdiag.size(), (int)Rdiag.size());
+    for (size_t i = 0; i < Rdiag.size(); i++) R((int)i, (int)i) = Rdiag[i];
+    return R;
+}
+
+Vec System::getMuVector(bool sparse) {  // System.cpp:321-339
+    const int nt = nb_target_var_;
+    if (sparse) {
+        Vec mu(nt * keypoints.size(), 0.0);
+        for (size_t i = 0; i < keypoints.size(); i++) {
+            const Vec s = keypoints[i]->getState();
+            std::copy(s.begin(), s.end(), mu.begin() + i * nt);
+        }
+        return mu;
+    }
+    Vec mu((size_t)horizon_ * nt, 0.0);
+    for (auto& kp : keypoints) {
+        const Vec s = kp->getState();
+        std::copy(s.begin(), s.end(), mu.begin() + (size_t)kp->getTimestep() * nt);
+    }
+    return mu;
+}
+
+Mat System::getQMatrix(bool sparse) {  // System.cpp:341-361
+    const int nq = nb_Q_var_;
+    const int n = sparse ? (int)keypoints.size() * nq : horizon_ * nq;
+    Mat Q(n, n);
+    for (size_t i = 0; i < keypoints.size(); i++) {
+        const Mat P = keypoints[i]->getPrecision();
+        const int o = sparse ? (int)i * nq : keypoints[i]->getTimestep() * nq;
+        for (int a = 0; a < nq; a++)
+            for (int b = 0; b < nq; b++) Q(o + a, o + b) = P(a, b);
+    }
+    return Q;
+}
+
+void System::lower(ilqr_problem_desc* d) const {
+    ilqr_desc_defaults(d);
+    if (!r->lowerChain(d)) throw std::runtime_error("[ilqr_hip] this SimulationInterface cannot be lowered to the device (only sim::KDLRobot chains can)");
+    d->kind = kind_;
+    d->nb_deriv = nb_deriv_;
+    d->horizon = horizon_;
+    d->dt = dt_;
+    if ((int)Rdiag.size() != nb_ctrl_var_) throw std::runtime_error("[System] RtDiag must have nb_ctrl_var entries");
+    for (int i = 0; i < nb_ctrl_var_; i++) d->R_diag[i] = Rdiag[i];
+    d->limits_set = limits_set_ ? 1 : 0;
+    d->penalty = penalty_;
+    for (size_t i = 0; i < state_max_.size(); i++) {
+        d->state_max[i] = state_max_[i];
+        d->state_min[i] = state_min_[i];
+        d->limit_weight[i] = joint_limits_weight_[i];
+    }
+    if (keypoints.size() > ILQR_MAX_KP) throw std::runtime_error("[ilqr_hip] too many keypoints for the device descriptor");
+    d->n_kp = (int)keypoints.size();
+    for (size_t k = 0; k < keypoints.size(); k++) {
+        if (k > 0 && keypoints[k]->getTimestep() == keypoints[k - 1]->getTimestep())
+            throw std::runtime_error("[ilqr_hip] two keypoints share a timestep: not supported on the device");
+        d->kp_timestep[k] = keypoints[k]->getTimestep();
+        const Mat P = keypoints[k]->getPrecision();
+        if (P.rows != nb_Q_var_ || P.cols != nb_Q_var_) throw std::runtime_error("[System] keypoint precision must be nb_Q_var x nb_Q_var");
+        for (int a = 0; a < nb_Q_var_; a++)
+            for (int b = 0; b < nb_Q_var_; b++) d->kp_Q[k][a * nb_Q_var_ + b] = P(a, b);
+    }
+}
+
+PosOrnPlannerSys::PosOrnPlannerSys(const std::shared_ptr<sim::SimulationInterface>& r, const std::vector<std::shared_ptr<Keypoint>>& kps, const Vec& Rt,
+                                   const Vec& qMax, const Vec& qMin, const Vec& dqMax, const Vec& dqMin, int horizon, int nb_deriv, double dt)
+    : System(r, kps, Rt, qMax, qMin, dqMax, dqMin, horizon, nb_deriv, {"POS_ORN"}) { localInit(dt); }
+PosOrnPlannerSys::PosOrnPlannerSys(const std::shared_ptr<sim::SimulationInterface>& r, const std::vector<std::shared_ptr<Keypoint>>& kps, const Vec& Rt,
+                                   const Vec& qMax, const Vec& qMin, int horizon, int nb_deriv, double dt)
+    : System(r, kps, Rt, qMax, qMin, Vec(), Vec(), horizon, nb_deriv, {"POS_ORN"}) { localInit(dt); }
+PosOrnPlannerSys::PosOrnPlannerSys(const std::shared_ptr<sim::SimulationInterface>& r, const std::vector<std::shared_ptr<Keypoint>>& kps, const Vec& Rt,
+                                   int horizon, int nb_deriv, double dt)
+    : System(r, kps, Rt, horizon, nb_deriv, {"POS_ORN"}) { localInit(dt); }
+
+void PosOrnPlannerSys::localInit(double dt) {  // PosOrnPlannerSys.cpp:54-78
+    kind_ = ILQR_SYS_POS_ORN;
+    dt_ = dt;
+    q0_ = r->getJointsPos();
+    dq0_ = r->getJointsVel();
+    f_x0_.clear();
+    x0_ = q0_;
+    append(f_x0_, r->getEEPosition());
+    append(f_x0_, r->getEEOrnQuat());
+    if (nb_deriv_ != 1) {
+        append(f_x0_, r->getEEVelocity());
+        append(f_x0_, r->getEEAngVelQuat());
+        append(x0_, dq0_);
+    }
+    nb_state_var_ = (int)x0_.size();
+    nb_ctrl_var_ = r->getDOF();
+    nb_target_var_ = (int)f_x0_.size();
+    nb_Q_var_ = nb_target_var_ - nb_deriv_;
+}
+Vec PosOrnPlannerSys::getState() {
+    Vec xk = r->getJointsPos();
+    if (nb_deriv_ != 1) append(xk, r->getJointsVel());
+    return xk;
+}
+void PosOrnPlannerSys::reset() { r->setConfiguration(q0_, dq0_); }
+
+PosOrnTimePlannerSys::PosOrnTimePlannerSys(const std::shared_ptr<sim::SimulationInterface>& r, const std::vector<std::shared_ptr<Keypoint>>& kps, const Vec& Rt,
+                                           const Vec& qMax, const Vec& qMin, const Vec& dqMax, const Vec& dqMin, int horizon, int nb_deriv)
+    : System(r, kps, Rt, qMax, qMin, dqMax, dqMin, horizon, nb_deriv, {"POS_ORN_TIME"}) { localInit(); }
+PosOrnTimePlannerSys::PosOrnTimePlannerSys(const std::shared_ptr<sim::SimulationInterface>& r, const std::vector<std::shared_ptr<Keypoint>>& kps, const Vec& Rt,
+                                           const Vec& qMax, const Vec& qMin, int horizon, int nb_deriv)
+    : System(r, kps, Rt, qMax, qMin, Vec(), Vec(), horizon, nb_deriv, {"POS_ORN_TIME"}) { localInit(); }
+PosOrnTimePlannerSys::PosOrnTimePlannerSys(const std::shared_ptr<sim::SimulationInterface>& r, const std::vector<std::shared_ptr<Keypoint>>& kps, const Vec& Rt,
+                                           int horizon, int nb_deriv)
+    : System(r, kps, Rt, horizon, nb_deriv, {"POS_ORN_TIME"}) { localInit(); }
+
+void PosOrnTimePlannerSys::localInit() {  // PosOrnTimePlannerSys.cpp:50-83
+    kind_ = ILQR_SYS_POS_ORN_TIME;
+    dt_ = 0;
+    q0_ = r->getJointsPos();
+    dq0_ = r->getJointsVel();
+    f_x0_.clear();
+    x0_ = q0_;
+    append(f_x0_, r->getEEPosition());
+    append(f_x0_, r->getEEOrnQuat());
+    if (nb_deriv_ != 1) {
+        append(f_x0_, r->getEEVelocity());
+        append(f_x0_, r->getEEAngVelQuat());
+        append(x0_, dq0_);
+    }
+    f_x0_.push_back(0);
+    x0_.push_back(0);
+    nb_state_var_ = (int)x0_.size();
+    nb_ctrl_var_ = r->getDOF() + 1;
+    nb_target_var_ = (int)f_x0_.size();
+    nb_Q_var_ = nb_target_var_ - nb_deriv_;
+    state_max_.push_back(0);  // the time state is never limited (weight 0)
+    state_min_.push_back(0);
+    joint_limits_weight_.push_back(0);
+}
+Vec PosOrnTimePlannerSys::getState() {
+    Vec xk = r->getJointsPos();
+    if (nb_deriv_ != 1) append(xk, r->getJointsVel());
+    xk.push_back(r->getTime());
+    return xk;
+}
+void PosOrnTimePlannerSys::reset() { r->setConfiguration(q0_, dq0_); }
+}  // namespace sys
+
+// ------------------------------------------------------------------------------------------------ solvers
+
+namespace solver {
+
+struct ProblemGuard {
+    ilqr_problem* p = nullptr;
+    ~ProblemGuard() { if (p) ilqr_problem_destroy(p); }
+};
+
+static std::string fmt(double v) {
+    std::ostringstream o;
+    o << v;
+    return o.str();
+}
+
+// Lower `s`, upload the per-instance inputs, run `solve`, read everything back.
+static BatchResult run_batch(sys::System& s, const BatchInputs& in, int nb_iter, bool gains, const ilqr_problem_desc* override_desc,
+                             const std::function<void(ilqr_problem*)>& pre_solve, const std::function<void(ilqr_problem*)>& solve,
+                             const std::function<void(ilqr_problem*)>& post_solve) {
+    ilqr_problem_desc d;
+    if (override_desc) d = *override_desc;
+    else s.lower(&d);
+    ilqr_dims dm;
+    if (ilqr_dims_of(&d, &dm)) throw std::runtime_error("[ilqr_hip] unsupported system for the device");
+    ilqr_ctx* ctx = device_context();
+    const int B = in.B, T = d.horizon, dof = d.dof;
+    if (B <= 0) throw std::runtime_error("[ilqr_hip] batch must be positive");
+    ProblemGuard g;
+    check(ilqr_problem_create(ctx, &d, B, &g.p));
+    auto tile = [&](const Vec& v, size_t per) {
+        std::vector<double> o((size_t)B * per);
+        for (int b = 0; b < B; b++) std::copy(v.begin(), v.begin() + per, o.begin() + (size_t)b * per);
+        return o;
+    };
+    std::vector<double> q0 = in.q0.empty() ? tile(s.q0(), dof) : in.q0, dq0 = in.dq0.empty() ? tile(s.dq0(), dof) : in.dq0;
+    if (q0.size() != (size_t)B * dof || dq0.size() != (size_t)B * dof) throw std::runtime_error("[ilqr_hip] q0/dq0 must be B x dof");
+    check(ilqr_problem_set_init_state(g.p, q0.data(), dq0.data()));
+    const auto& kps = s.getKeypoints();
+    for (size_t k = 0; k < kps.size(); k++) {
+        std::vector<double> tg = (k < in.kp_targets.size() && !in.kp_targets[k].empty()) ? in.kp_targets[k] : tile(kps[k]->targetFx(), dm.n_f);
+        if (tg.size() != (size_t)B * dm.n_f) throw std::runtime_error("[ilqr_hip] keypoint targets must be B x nb_target_var");
+        check(ilqr_problem_set_keypoint_targets(g.p, (int)k, tg.data()));
+    }
+    const size_t nU = (size_t)(T - 1) * dm.n_u;
+    std::vector<double> U0;
+    if (in.U0.size() == nU * B) U0 = in.U0;
+    else if (in.U0.size() == nU) U0 = tile(in.U0, nU);
+    else throw std::runtime_error("[ilqr_hip] U0 must be (T-1) x nb_ctrl_var per instance");
+    check(ilqr_problem_set_controls(g.p, U0.data()));
+    if (pre_solve) pre_solve(g.p);
+    const auto t0 = std::chrono::steady_clock::now();
+    solve(g.p);
+    check(ilqr_ctx_synchronize(ctx));
+    const std::chrono::duration<double> el = std::chrono::steady_clock::now() - t0;
+    BatchResult r;
+    r.B = B; r.T = T; r.n_x = dm.n_x; r.n_u = dm.n_u; r.n_f = dm.n_f; r.nb_iter = nb_iter; r.seconds = el.count();
+    r.X.resize((size_t)B * T * dm.n_x);
+    r.U.resize((size_t)B * nU);
+    r.cost.resize(B); r.alpha.resize(B); r.iters.resize(B); r.status.resize(B);
+    check(ilqr_problem_get_X(g.p, r.X.data()));
+    check(ilqr_problem_get_U(g.p, r.U.data()));
+    check(ilqr_problem_get_cost(g.p, r.cost.data()));
+    check(ilqr_problem_get_alpha(g.p, r.alpha.data()));
+    check(ilqr_problem_get_iters(g.p, r.iters.data()));
+    check(ilqr_problem_get_status(g.p, r.status.data()));
+    if (in.want_fX) { r.fX.resize((size_t)B * T * dm.n_f); check(ilqr_problem_get_fX(g.p, r.fX.data())); }
+    if (gains && in.want_gains && nb_iter > 0) {
+        r.K.resize((size_t)B * nU * dm.n_x);
+        r.d.resize((size_t)B * nU);
+        check(ilqr_problem_get_K(g.p, r.K.data()));
+        check(ilqr_problem_get_d(g.p, r.d.data()));
+    }
+    if (nb_iter > 0) {
+        r.cost_trace.resize((size_t)B * nb_iter);
+        r.alpha_trace.resize((size_t)B * nb_iter);
+        check(ilqr_problem_get_trace(g.p, r.cost_trace.data(), r.alpha_trace.data(), nb_iter));
+    }
+    if (post_solve) post_solve(g.p);
+    return r;
+}
+
+// the per-iteration stream of the reference ("Iteration i, Cost: c, alpha= a[, time= t]") for instance 0
+static void emit_trace(const BatchResult& r, CallBackMessage* cb, bool with_time) {
+    const int n = r.iters.empty() ? 0 : r.iters[0];
+    for (int i = 0; i < n; i++) {
+        std::string msg = "Iteration " + std::to_string(i + 1) + ", Cost: " + fmt(r.cost_trace[i]) + ", alpha= " + fmt(r.alpha_trace[i]);
+        if (with_time) msg += ", time= " + fmt(r.seconds / std::max(1, n));
+        if (cb == nullptr) std::cout << msg << std::endl;
+        else cb->notify(msg);
+    }
+}
+
+static std::vector<double> flatten(const std::vector<Vec>& U0, int T, int nu) {
+    if ((int)U0.size() != T - 1) throw std::runtime_error("[solver] U0 must hold horizon-1 control vectors");
+    std::vector<double> o;
+    for (auto& u : U0) {
+        if ((int)u.size() != nu) throw std::runtime_error("[solver] each U0 entry must have nb_ctrl_var entries");
+        o.insert(o.end(), u.begin(), u.end());
+    }
+    return o;
+}
+static std::vector<Vec> rows_of(const std::vector<double>& v, int n, int w) {
+    std::vector<Vec> o(n);
+    for (int i = 0; i < n; i++) o[i] = Vec(v.begin() + (size_t)i * w, v.begin() + (size_t)(i + 1) * w);
+    return o;
+}
+
+BatchResult ILQRRecursive::solveBatch(const BatchInputs& in, int nb_iter, bool line_search, bool early_stop) {
+    return run_batch(*s, in, nb_iter, true, nullptr, nullptr, [&](ilqr_problem* p) { check(ilqr_solve_recursive(p, nb_iter, line_search, early_stop)); }, nullptr);
+}
+
+std::tuple<std::vector<Vec>, std::vector<Vec>, std::vector<Vec>, std::vector<Mat>, std::vector<Vec>, double> ILQRRecursive::solve(
+    const std::vector<Vec>& U0, int nb_iter, bool line_search, bool early_stop, CallBackMessage* cb) {  // ILQRRecursive.cpp:21-181
+    BatchInputs in;
+    in.B = 1;
+    in.U0 = flatten(U0, s->getHorizon(), s->getNbCtrlVar());
+    const BatchResult r = solveBatch(in, nb_iter, line_search, early_stop);
+    emit_trace(r, cb, true);
+    s->reset();
+    const int T = r.T;
+    std::vector<Mat> Ks;
+    std::vector<Vec> ds;
+    if (!r.K.empty()) {
+        for (int k = 0; k < T - 1; k++) {
+            Mat K(r.n_u, r.n_x);
+            std::copy(r.K.begin() + (size_t)k * r.n_u * r.n_x, r.K.begin() + (size_t)(k + 1) * r.n_u * r.n_x, K.d.begin());
+            Ks.push_back(K);
+        }
+        ds = rows_of(r.d, T - 1, r.n_u);
+    }
+    return std::make_tuple(rows_of(r.X, T, r.n_x), rows_of(r.fX, T, r.n_f), rows_of(r.U, T - 1, r.n_u), Ks, ds, r.cost[0]);
+}
+
+AL_ILQR::AL_ILQR(const std::shared_ptr<sys::System>& s_, const std::vector<Constraint>& ineq, const std::vector<Vec>& initLambda)
+    : s(s_), inequality(ineq), multipliers(initLambda) {}
+
+BatchResult AL_ILQR::solveBatch(const BatchInputs& in, int nb_iter, int lag, double penalty, double scaling, bool line_search, bool early_stop) {
+    const int T = s->getHorizon(), ns = s->getNbStateVar() + s->getNbCtrlVar();
+    if ((int)inequality.size() != T - 1 || (int)multipliers.size() != T - 1)
+        throw std::runtime_error("[AL_ILQR] need one Constraint and one multiplier vector per timestep (horizon-1)");
+    const int m_full = inequality[0].A.rows;
+    for (auto& c : inequality)
+        if (c.A.rows != m_full || c.A.cols != ns || (int)c.b.size() != m_full)
+            throw std::runtime_error("[AL_ILQR] every Constraint must be m x (nb_state_var+nb_ctrl_var) with an m-vector b");
+    // rows that are identically zero for every k contribute nothing to the backward pass: they are dropped on the device
+    // and their multipliers follow lambda <- max(0, lambda + penalty * (-b)) on the host (AL-ILQR.cpp:202-208)
+    std::vector<int> keep;
+    for (int r_ = 0; r_ < m_full; r_++) {
+        bool nz = false;
+        for (auto& c : inequality)
+            for (int j = 0; j < ns && !nz; j++) nz = c.A(r_, j) != 0.0;
+        if (nz) keep.push_back(r_);
+    }
+    const int m = (int)keep.size();
+    if (m == 0) throw std::runtime_error("[AL_ILQR] all constraint rows are zero");
+    bool per_step = false;
+    for (int k = 1; k < T - 1 && !per_step; k++)
+        for (int r_ : keep) {
+            for (int j = 0; j < ns; j++) per_step = per_step || inequality[k].A(r_, j) != inequality[0].A(r_, j);
+            per_step = per_step || inequality[k].b[r_] != inequality[0].b[r_];
+        }
+    const int nk = per_step ? T - 1 : 1;
+    std::vector<double> A((size_t)nk * m * ns), b((size_t)nk * m), lam((size_t)in.B * (T - 1) * m);
+    for (int k = 0; k < nk; k++)
+        for (int i = 0; i < m; i++) {
+            for (int j = 0; j < ns; j++) A[((size_t)k * m + i) * ns + j] = inequality[k].A(keep[i], j);
+            b[(size_t)k * m + i] = inequality[k].b[keep[i]];
+        }
+    for (int bi = 0; bi < in.B; bi++)
+        for (int k = 0; k < T - 1; k++)
+            for (int i = 0; i < m; i++) lam[((size_t)bi * (T - 1) + k) * m + i] = multipliers[k][keep[i]];
+    std::vector<double> lam_out;
+    BatchResult r = run_batch(
+        *s, in, nb_iter, false, nullptr, [&](ilqr_problem* p) { check(ilqr_problem_set_constraints(p, m, per_step ? 1 : 0, A.data(), b.data(), lam.data())); },
+        [&](ilqr_problem* p) { check(ilqr_solve_al(p, nb_iter, lag, penalty, scaling, line_search, early_stop)); },
+        [&](ilqr_problem* p) {
+            lam_out.resize(lam.size());
+            check(ilqr_problem_get_lambda(p, lam_out.data()));
+        });
+    // persist instance 0's multipliers (the reference's `multipliers` member)
+    double pen = penalty;
+    const int it_run = r.iters.empty() ? 0 : r.iters[0];
+    for (int it = 0; it < it_run; it++) {
+        if ((it + 1) % lag == 0) {
+            pen *= scaling;
+            for (int k = 0; k < T - 1; k++)
+                for (int r_ = 0; r_ < m_full; r_++)
+                    if (std::find(keep.begin(), keep.end(), r_) == keep.end())
+                        multipliers[k][r_] = std::max(0.0, multipliers[k][r_] + pen * (0.0 - inequality[k].b[r_]));
+        }
+    }
+    for (int k = 0; k < T - 1; k++)
+        for (int i = 0; i < m; i++) multipliers[k][keep[i]] = lam_out[(size_t)k * m + i];
+    return r;
+}
+
+std::tuple<std::vector<Vec>, std::vector<Vec>, std::vector<Vec>> AL_ILQR::solve(const std::vector<Vec>& U0, int nb_iter, int lag, double penalty, double scaling,
+                                                                              bool line_search, bool early_stop, CallBackMessage* cb) {  // AL-ILQR.cpp:50-232
+    BatchInputs in;
+    in.B = 1;
+    in.U0 = flatten(U0, s->getHorizon(), s->getNbCtrlVar());
+    const BatchResult r = solveBatch(in, nb_iter, lag, penalty, scaling, line_search, early_stop);
+    emit_trace(r, cb, true);
+    s->reset();
+    return std::make_tuple(rows_of(r.X, r.T, r.n_x), rows_of(r.fX, r.T, r.n_f), rows_of(r.U, r.T - 1, r.n_u));
+}
+
+BatchILQRCP::BatchILQRCP(const std::shared_ptr<sys::System>& s_, const Mat& Q_, const Mat& psi) : s(s_), PSI(psi), Q(Q_), custom_Q(true) {}
+BatchILQRCP::BatchILQRCP(const std::shared_ptr<sys::System>& s_, const Mat& psi) : s(s_), PSI(psi), custom_Q(false) {}
+
+BatchResult BatchILQRCP::solveBatch(const BatchInputs& in, int nb_iter, bool early_stop) {
+    const int T = s->getHorizon(), nu = s->getNbCtrlVar();
+    if (PSI.rows != (T - 1) * nu) throw std::runtime_error("[BatchILQRCP] psi must have (horizon-1)*nb_ctrl_var rows");
+    ilqr_problem_desc d;
+    s->lower(&d);
+    if (custom_Q) {  // BatchILQRCP.cpp:21-26: a user Q replaces the keypoints' precisions; the device takes its diagonal blocks
+        const int nq = s->getNbQVar(), nkp = d.n_kp;
+        if (Q.rows != nkp * nq || Q.cols != nkp * nq) throw std::runtime_error("[BatchILQRCP] Q must be (n_keypoints*nb_Q_var) square (sparse form)");
+        for (int a = 0; a < Q.rows; a++)
+            for (int b = 0; b < Q.cols; b++) {
+                if (a / nq == b / nq) d.kp_Q[a / nq][(a % nq) * nq + (b % nq)] = Q(a, b);
+                else if (Q(a, b) != 0.0) throw std::runtime_error("[ilqr_hip] a Q coupling different keypoints is not supported on the device");
+            }
+    }
+    BatchInputs in2 = in;
+    in2.want_gains = false;
+    return run_batch(*s, in2, nb_iter, false, &d, nullptr,
+                     [&](ilqr_problem* p) { check(ilqr_solve_batch_cp(p, PSI.d.data(), PSI.cols, nb_iter, early_stop)); }, nullptr);
+}
+
+Vec BatchILQRCP::solve(int nb_iter, const Vec& u0, bool early_stop, CallBackMessage* cb) {  // BatchILQRCP.cpp:109-175
+    BatchInputs in;
+    in.B = 1;
+    in.U0 = u0;
+    in.want_fX = false;
+    const BatchResult r = solveBatch(in, nb_iter, early_stop);
+    emit_trace(r, cb, false);
+    s->reset();
+    return r.U;
+}
+
+}  // namespace solver
+}  // namespace ilqr_planner

@@ -1,0 +1,307 @@
+// ilqr_host.hpp -- C++ host mirror of the reference's user-facing classes for the batched iLQR hot path.
+//
+// Same names, argument meaning and error behaviour (std::runtime_error) as idiap/ilqr_planner:
+//   sim::SimulationInterface / sim::KDLRobot          include/ilqr_planner/sim/{SimulationInterface,KDLRobot}.h
+//   sys::Keypoint / PosOrnKeypoint / SpacetimeKeypoint include/ilqr_planner/system/*Keypoint.h
+//   sys::System / PosOrnPlannerSys / PosOrnTimePlannerSys  include/ilqr_planner/system/{System,PosOrn*PlannerSys}.h
+//   solver::ILQRRecursive / AL_ILQR / BatchILQRCP      include/ilqr_planner/solver/*.h
+//   primitives, Sd, CallBackMessage                   include/ilqr_planner/utils/*.h
+// No Eigen (absent from this image): Vec/Mat are plain row-major containers.  These classes hold state and LOWER it to
+// the POD descriptor of include/ilqr_hip.h; every solve and every kinematics evaluation runs on the GPU through that C
+// ABI -- there is no host solver.  What is NOT mirrored: the System virtuals the reference's own CPU loops call
+// (forwardPass, cost*, getFxJac, fpBatch), Robot2D, TransformedSimulationInterface, SequentialSystem, JointSpace*,
+// BatchILQR (no PSI), LQT -- see DESIGN.md.
+#pragma once
+
+#include <memory>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../../include/ilqr_hip.h"
+
+namespace ilqr_planner {
+
+using Vec = std::vector<double>;
+struct Mat {
+    int rows = 0, cols = 0;
+    std::vector<double> d;  // row-major
+    Mat() {}
+    Mat(int r, int c) : rows(r), cols(c), d((size_t)r * c, 0.0) {}
+    double& operator()(int r, int c) { return d[(size_t)r * cols + c]; }
+    double operator()(int r, int c) const { return d[(size_t)r * cols + c]; }
+    static Mat Identity(int n) { Mat m(n, n); for (int i = 0; i < n; i++) m(i, i) = 1; return m; }
+};
+
+class CallBackMessage {  // include/ilqr_planner/utils/CallbackMessage.h:12-16
+public:
+    virtual ~CallBackMessage() {}
+    virtual void notify(const std::string& msg) = 0;
+};
+
+// process-wide device context (one MI355X per process, as one-rank-per-GPU launches expect)
+ilqr_ctx* device_context();
+void check(int rc);  // non-zero -> std::runtime_error(ilqr_last_error)
+
+namespace Sd {  // include/ilqr_planner/utils/sd.h
+Mat dQuatToDxJac(const Vec& q);
+Vec expMap(Vec base, const Vec& u);
+double distance(const Vec& x, const Vec& y);
+Vec logMap(Vec base, Vec y);
+Vec transport(const Vec& v, const Vec& base1, const Vec& base2);
+}  // namespace Sd
+
+Mat buildPsiRBF(int dim, int K);  // src/utils/primitives.cpp:19-96
+Mat buildPsiBernstein(int dim, int K);
+Mat buildPsiUnitstep(int dim, int K);
+Mat buildPsiSawtooth(int dim, int K);
+Mat buildPsiLinear(int dim, int K);
+
+namespace sim {
+class SimulationInterface {  // SimulationInterface.h:13-124
+public:
+    virtual ~SimulationInterface() {}
+    virtual void updateKinematics() = 0;
+    Mat Jt();
+    Mat Jr();
+    virtual Mat J() { return Jac; }
+    Mat dQuatToDxJac(const Vec& quat) { return Sd::dQuatToDxJac(quat); }
+    virtual void sendAcc(double dt, const Vec& ddq, bool updateKin = true);
+    virtual void sendVel(double dt, const Vec& dq, bool updateKin = true);
+    virtual Vec getEEPosition() { return x; }
+    virtual Vec getEEVelocity() { return dx; }
+    virtual Vec getEEAngVel() { return w; }
+    Vec getEEAngVelQuat();
+    virtual Vec getEEOrnQuat() { return ornQuat; }
+    Vec getJointsPos() { return q; }
+    Vec getJointsVel() { return dq; }
+    int getDOF() { return dof; }
+    int getNbCarDim() { return nbCarDim; }
+    double getTime() { return t; }
+    virtual void setTime(double time) { t = time; }
+    virtual void setConfiguration(const Vec& q, const Vec& dq, bool reset_time = true);
+    // lowering hook: fill the chain part of the descriptor; false if this simulator cannot run on the device
+    virtual bool lowerChain(ilqr_problem_desc*) const { return false; }
+
+protected:
+    Vec q, dq, ddq, x, dx, ornQuat, w;
+    Mat Jac;
+    int dof = 0, nbCarDim = 3;
+    double t = 0;
+};
+
+class KDLRobot : public SimulationInterface {  // KDLRobot.h:22-57
+public:
+    KDLRobot(const std::string& urdf, const std::string& baseFrame, const std::string& tipFrame, const Vec& q, const Vec& dq,
+             const Vec& transform_rpy, const Vec& transform_xyz, const bool& is_path);
+    KDLRobot(const std::string& urdf, const std::string& baseFrame, const std::string& tipFrame, const Vec& q, const Vec& dq)
+        : KDLRobot(urdf, baseFrame, tipFrame, q, dq, Vec(3, 0.0), Vec(3, 0.0), true) {}
+    KDLRobot(const std::string& urdf, const std::string& baseFrame, const std::string& tipFrame, const Vec& q, const Vec& dq,
+             const Vec& transform_rpy, const Vec& transform_xyz)
+        : KDLRobot(urdf, baseFrame, tipFrame, q, dq, transform_rpy, transform_xyz, true) {}
+    void updateKinematics() override;  // one-configuration call of ilqr_fk_batch (the FK kernel), then dx = Jt dq, w = Jr dq
+    bool lowerChain(ilqr_problem_desc* d) const override;
+    Vec jointLowerLimits() const { return lower_; }
+    Vec jointUpperLimits() const { return upper_; }
+
+protected:
+    ilqr_problem_desc chain_;  // only the chain fields are meaningful
+    Vec lower_, upper_;
+};
+}  // namespace sim
+
+namespace sys {
+class Keypoint {  // Keypoint.h:15-41
+public:
+    enum KpType { FIRST_ORDER = 1, SECOND_ORDER = 2 };
+    Keypoint(int timestep, KpType type, const std::string& TAG) : TAG_(TAG), type_(type), timestep_(timestep) {}
+    virtual ~Keypoint() {}
+    virtual Vec diff(const Vec& state) const = 0;
+    virtual Vec getState() const = 0;
+    virtual Mat getPrecision() const = 0;
+    virtual Vec targetFx() const = 0;  // target in f(x) order [p, quat, (dp, dquat), (t)] -- what the device consumes
+    int getTimestep() const { return timestep_; }
+    std::string getTAG() const { return TAG_; }
+    KpType getType() const { return type_; }
+
+protected:
+    std::string TAG_;
+    KpType type_;
+    int timestep_;
+};
+
+class PosOrnKeypoint : public Keypoint {  // PosOrnKeypoint.h:15-60
+public:
+    PosOrnKeypoint(const Vec& position, const Vec& orientation, const Mat& precision, const int& timestep);
+    PosOrnKeypoint(const Vec& position, const Vec& dposition, const Vec& orientation, const Vec& dorientation, const Mat& precision, const int& timestep);
+    Vec getPosition() const { return position_; }
+    Vec getOrientation() const { return orientation_; }
+    Mat getPrecision() const override { return precision_; }
+    Vec diff(const Vec& state) const override;
+    Vec getState() const override;
+    Vec targetFx() const override;
+
+protected:
+    Vec position_, orientation_, dposition_, dorientation_;
+    Mat precision_;
+    int state_size_;
+};
+
+class SpacetimeKeypoint : public PosOrnKeypoint {  // SpacetimeKeypoint.h:15-45
+public:
+    SpacetimeKeypoint(const Vec& position, const Vec& orientation, const Mat& precision, const double& continuous_time, const int& timestep);
+    SpacetimeKeypoint(const Vec& position, const Vec& dposition, const Vec& orientation, const Vec& dorientation, const Mat& precision,
+                      const double& continuous_time, const int& timestep);
+    double getContinuousTime() { return continuous_time_; }
+    Vec diff(const Vec& state) const override;
+    Vec getState() const override;
+    Vec targetFx() const override;
+
+protected:
+    double continuous_time_;
+};
+
+class System {  // System.h:28-194
+public:
+    System(const std::shared_ptr<sim::SimulationInterface>& r, const std::vector<std::shared_ptr<Keypoint>>& keypoints, const Vec& RtDiag,
+           const Vec& qMax, const Vec& qMin, const Vec& dqMax, const Vec& dqMin, int horizon, int nb_deriv, const std::vector<std::string>& tags);
+    System(const std::shared_ptr<sim::SimulationInterface>& r, const std::vector<std::shared_ptr<Keypoint>>& keypoints, const Vec& RtDiag,
+           int horizon, int nb_deriv, const std::vector<std::string>& tags);
+    virtual ~System() {}
+    Vec getMuVector(bool sparse);
+    Mat getQMatrix(bool sparse);
+    Mat getRt();
+    int getNbStateVar() { return nb_state_var_; }
+    int getNbCtrlVar() { return nb_ctrl_var_; }
+    int getNbTargetVar() { return nb_target_var_; }
+    int getNbQVar() { return nb_Q_var_; }
+    int getHorizon() { return horizon_; }
+    std::vector<int> getKpIndexes();
+    Vec getInitState() { return x0_; }
+    Vec getInitFoXState() { return f_x0_; }
+    virtual Vec getState() = 0;
+    virtual void reset() = 0;
+    std::shared_ptr<sim::SimulationInterface> robot() { return r; }
+    const std::vector<std::shared_ptr<Keypoint>>& getKeypoints() const { return keypoints; }
+    // Lowering to the C ABI's POD descriptor.  Throws for systems the device cannot run.
+    virtual void lower(ilqr_problem_desc* d) const;
+    // per-instance pieces for B = 1: q0, dq0 captured by localInit
+    Vec q0() const { return q0_; }
+    Vec dq0() const { return dq0_; }
+
+protected:
+    void init();
+    void checkKeypoints();
+    std::shared_ptr<sim::SimulationInterface> r;
+    std::vector<std::shared_ptr<Keypoint>> keypoints;
+    Vec Rdiag;
+    Vec state_max_, state_min_;
+    std::vector<int> joint_limits_weight_;
+    Vec q0_, dq0_, x0_, f_x0_;
+    int horizon_, nb_deriv_;
+    int nb_state_var_ = 0, nb_ctrl_var_ = 0, nb_target_var_ = 0, nb_Q_var_ = 0;
+    double penalty_ = 0, dt_ = 0;
+    bool limits_set_ = false;
+    int kind_ = ILQR_SYS_POS_ORN;
+    std::vector<std::string> EXPECTED_KP_TAGS_;
+};
+
+class PosOrnPlannerSys : public System {  // PosOrnPlannerSys.h
+public:
+    PosOrnPlannerSys(const std::shared_ptr<sim::SimulationInterface>& r, const std::vector<std::shared_ptr<Keypoint>>& keypoints, const Vec& RtDiag,
+                     const Vec& qMax, const Vec& qMin, const Vec& dqMax, const Vec& dqMin, int horizon, int nb_deriv, double dt);
+    PosOrnPlannerSys(const std::shared_ptr<sim::SimulationInterface>& r, const std::vector<std::shared_ptr<Keypoint>>& keypoints, const Vec& RtDiag,
+                     const Vec& qMax, const Vec& qMin, int horizon, int nb_deriv, double dt);
+    PosOrnPlannerSys(const std::shared_ptr<sim::SimulationInterface>& r, const std::vector<std::shared_ptr<Keypoint>>& keypoints, const Vec& RtDiag,
+                     int horizon, int nb_deriv, double dt);
+    Vec getState() override;
+    void reset() override;
+
+protected:
+    void localInit(double dt);
+};
+
+class PosOrnTimePlannerSys : public System {  // PosOrnTimePlannerSys.h
+public:
+    PosOrnTimePlannerSys(const std::shared_ptr<sim::SimulationInterface>& r, const std::vector<std::shared_ptr<Keypoint>>& keypoints, const Vec& RtDiag,
+                         const Vec& qMax, const Vec& qMin, const Vec& dqMax, const Vec& dqMin, int horizon, int nb_deriv);
+    PosOrnTimePlannerSys(const std::shared_ptr<sim::SimulationInterface>& r, const std::vector<std::shared_ptr<Keypoint>>& keypoints, const Vec& RtDiag,
+                         const Vec& qMax, const Vec& qMin, int horizon, int nb_deriv);
+    PosOrnTimePlannerSys(const std::shared_ptr<sim::SimulationInterface>& r, const std::vector<std::shared_ptr<Keypoint>>& keypoints, const Vec& RtDiag,
+                         int horizon, int nb_deriv);
+    Vec getState() override;
+    void reset() override;
+
+protected:
+    void localInit();
+};
+}  // namespace sys
+
+namespace solver {
+
+// Result of a batched solve: instance b is what the reference's solve() would have returned for that instance.
+struct BatchResult {
+    int B = 0, T = 0, n_x = 0, n_u = 0, n_f = 0;
+    std::vector<double> X, fX, U, K, d;  // [B][T][n_x], [B][T][n_f], [B][T-1][n_u], [B][T-1][n_u][n_x], [B][T-1][n_u]
+    std::vector<double> cost, alpha;     // [B]
+    std::vector<int> iters, status;      // [B]
+    std::vector<double> cost_trace, alpha_trace;  // [B][nb_iter]
+    int nb_iter = 0;
+    double seconds = 0;
+};
+
+// Per-instance inputs of a batched solve; anything left empty takes the System's own value for every instance.
+struct BatchInputs {
+    int B = 1;
+    std::vector<double> q0, dq0;                    // [B][dof]
+    std::vector<std::vector<double>> kp_targets;    // per keypoint: [B][n_f] in f(x) order
+    std::vector<double> U0;                         // [B][T-1][n_u]  (or [T-1][n_u], broadcast)
+    bool want_fX = true, want_gains = true;
+};
+
+struct Constraint {  // AL-ILQR.h:20-23
+    Mat A;
+    Vec b;
+};
+
+class ILQRRecursive {  // ILQRRecursive.h:21-42
+public:
+    explicit ILQRRecursive(const std::shared_ptr<sys::System>& s) : s(s) {}
+    std::tuple<std::vector<Vec>, std::vector<Vec>, std::vector<Vec>, std::vector<Mat>, std::vector<Vec>, double> solve(
+        const std::vector<Vec>& U0, int nb_iter, bool line_search = true, bool early_stop = true, CallBackMessage* cb = nullptr);
+    BatchResult solveBatch(const BatchInputs& in, int nb_iter, bool line_search = true, bool early_stop = true);
+
+private:
+    std::shared_ptr<sys::System> s;
+};
+
+class AL_ILQR {  // AL-ILQR.h:25-72
+public:
+    AL_ILQR(const std::shared_ptr<sys::System>& s, const std::vector<Constraint>& inequality, const std::vector<Vec>& initLambda);
+    std::tuple<std::vector<Vec>, std::vector<Vec>, std::vector<Vec>> solve(const std::vector<Vec>& U0, int nb_iter, int lag_update_step, double penalty,
+                                                                          double scaling_factor, bool line_search = true, bool early_stop = false,
+                                                                          CallBackMessage* cb = nullptr);
+    BatchResult solveBatch(const BatchInputs& in, int nb_iter, int lag_update_step, double penalty, double scaling_factor, bool line_search = true,
+                           bool early_stop = false);
+
+private:
+    std::shared_ptr<sys::System> s;
+    std::vector<Constraint> inequality;
+    std::vector<Vec> multipliers;  // persists across solve() calls like the reference's member
+};
+
+class BatchILQRCP {  // BatchILQRCP.h:21-52
+public:
+    BatchILQRCP(const std::shared_ptr<sys::System>& s, const Mat& Q, const Mat& psi);
+    BatchILQRCP(const std::shared_ptr<sys::System>& s, const Mat& psi);
+    Vec solve(int nb_iter, const Vec& u0, bool early_stop = true, CallBackMessage* cb = nullptr);
+    BatchResult solveBatch(const BatchInputs& in, int nb_iter, bool early_stop = true);
+
+private:
+    std::shared_ptr<sys::System> s;
+    Mat PSI;
+    Mat Q;  // only the block-diagonal of the keypoints' precisions is supported on the device
+    bool custom_Q = false;
+};
+}  // namespace solver
+}  // namespace ilqr_planner

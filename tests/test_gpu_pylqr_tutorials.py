@@ -1,0 +1,158 @@
+"""The reference's tutorial notebooks as scripts, run against the PyLQR module built from this repo (API smoke + golden
+traces): the code below is what the notebooks' cells do (pylqr_planner/Tutorials/*.ipynb), with the URDF path swapped for
+the committed kinematic skeleton.  The message stream delivered to the CallBackMessage must equal the stored outputs."""
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+
+from tests.helpers import GOLDEN, ROOT, golden
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(ROOT, "ilqr_planner_amd", "pylqr"))
+
+URDF = os.path.join(GOLDEN, "panda_chain.urdf")
+LINE = re.compile(r"Iteration (\d+), Cost: (\S+), alpha= ([^,\s]+)")
+
+
+def _check_stream(lines, trace):
+    assert len(lines) == len(trace), (len(lines), len(trace))
+    for i, (l, (c_ref, a_ref)) in enumerate(zip(lines, trace)):
+        m = LINE.match(l)
+        assert m and int(m.group(1)) == i + 1, l
+        assert float(m.group(3)) == a_ref, l
+        if c_ref is None:
+            assert "nan" in m.group(2)
+        else:
+            assert abs(float(m.group(2)) - c_ref) <= 1.01e-6 * abs(c_ref) * 10 ** 0 + 10.0 ** (np.floor(np.log10(abs(c_ref))) - 5) * 1.01, l
+
+
+def _cb(capsys):
+    from PyLQR.utils import PythonCallbackMessage
+
+    return PythonCallbackMessage()
+
+
+def test_pos_orn_sys_tutorial(capsys):
+    from PyLQR.sim import KDLRobot
+    from PyLQR.solver import BatchILQRCP, ILQRRecursive
+    from PyLQR.system import PosOrnKeypoint, PosOrnPlannerSys
+    from PyLQR.utils import PythonCallbackMessage, primitives
+
+    g = golden()["cases"]["POS_ORN_SYS"]
+    dof, nb_state_var, nb_ctrl_var, nb_fox_var, horizon, dt = 7, 7, 7, 7, 100, 0.1
+    q0 = g["problem"]["q0"]
+    dq0 = [0] * dof
+    qMax = np.array([np.pi] * dof) * 10
+    rbt = KDLRobot(URDF, "panda_link0", "panda_tip", q0, dq0)
+    kps = []
+    for k in g["problem"]["keypoints"]:
+        kps.append(PosOrnKeypoint(np.array(k["pos"]), np.array(k["orn"]), np.diag(k["Qdiag"]), k["timestep"]))
+    cmd_penalties = (np.ones(nb_ctrl_var) * 1e-5).tolist()
+    sys_ = PosOrnPlannerSys(rbt, kps, cmd_penalties, qMax, -qMax, horizon, 1, dt)
+    assert (sys_.get_nb_state_var(), sys_.get_nb_ctrl_var(), sys_.get_nb_target_var(), sys_.get_horizon()) == (7, 7, 7, 100)
+    Q = sys_.get_Q_matrix(False)
+    mu = sys_.get_mu_vector(False)
+    assert Q.shape == (600, 600) and mu.shape == (700,) and Q[49 * 6 + 3, 49 * 6 + 3] == 0.1 and mu[99 * 7] == kps[1].get_position()[0]
+    u0 = np.tile(np.array([0] * nb_ctrl_var), horizon - 1)
+    psi = primitives.build_psi_unitstep(horizon - 1, 2)
+    PSI = np.kron(psi, np.identity(nb_ctrl_var))
+    planner1, planner2 = BatchILQRCP(sys_, PSI), ILQRRecursive(sys_)
+    cb = PythonCallbackMessage()
+    capsys.readouterr()
+
+    U1 = planner1.solve(10, u0, True, cb)
+    _check_stream(capsys.readouterr().out.strip().splitlines(), g["solves"][0]["trace"])
+    U1 = U1.reshape((horizon - 1, nb_ctrl_var))
+    rbt.set_conf(q0, dq0, True)  # the notebook's replay loop on the host simulator
+    F_X1 = np.zeros((horizon, nb_fox_var))
+    F_X1[0] = np.hstack((rbt.get_ee_pos(), rbt.get_ee_orn()))
+    for i in range(horizon - 1):
+        rbt.send_vel(dt, U1[i], True)
+        F_X1[i + 1] = np.hstack((rbt.get_ee_pos(), rbt.get_ee_orn()))
+    assert np.linalg.norm(F_X1[49, :3] - kps[0].get_position()) < 2e-2 and np.linalg.norm(F_X1[99, :3] - kps[1].get_position()) < 2e-2
+
+    X2, F_X2, U2, K2, k2, cost = planner2.solve(u0.reshape((-1, nb_ctrl_var)), 10, True, True, cb)
+    _check_stream(capsys.readouterr().out.strip().splitlines(), g["solves"][1]["trace"])
+    F_X2 = np.asarray(F_X2)
+    assert F_X2.shape == (100, 7) and np.asarray(X2).shape == (100, 7) and np.asarray(U2).shape == (99, 7)
+    assert np.asarray(K2).shape == (99, 7, 7) and np.asarray(k2).shape == (99, 7) and abs(cost - 9.80376e-07) < 1e-11
+    np.testing.assert_allclose(F_X2[99, :3], kps[1].get_position(), atol=2e-3)
+    np.testing.assert_allclose(rbt.get_q(), q0)  # the solver leaves the simulator at reset() (ILQRRecursive.cpp:179)
+
+
+def test_al_ilqr_tutorial(capsys):
+    from PyLQR.sim import KDLRobot
+    from PyLQR.solver import AL_ILQR, Constraint
+    from PyLQR.system import PosOrnKeypoint, PosOrnPlannerSys
+    from PyLQR.utils import PythonCallbackMessage
+
+    g = golden()["cases"]["POS_ORN_SYS_AL_ILQR"]
+    dof, horizon, dt = 7, 400, 0.01
+    q0, dq0 = g["problem"]["q0"], [0] * dof
+    qMax, dqMax = np.array([np.pi] * dof) * 10, np.array([10] * dof)
+    rbt = KDLRobot(URDF, "panda_link0", "panda_tip", q0, dq0)
+    kps = [PosOrnKeypoint(np.array(k["pos"]), np.array(k["orn"]), np.diag(k["Qdiag"]), k["timestep"]) for k in g["problem"]["keypoints"]]
+    sys_ = PosOrnPlannerSys(rbt, kps, (np.ones(7) * 1e-5).tolist(), qMax, -qMax, dqMax, -dqMax, horizon, 1, dt)
+    A = np.zeros((14, 14))
+    b = np.zeros(14)
+    A[5, 5] = 1
+    b[5] = 2.0
+    constraints, init_multipliers = [], []
+    for i in range(horizon - 1):
+        c = Constraint()
+        c.A = A
+        c.b = b
+        constraints += [c]
+        init_multipliers += [b]
+    planner2 = AL_ILQR(sys_, constraints, init_multipliers)
+    cb = PythonCallbackMessage()
+    capsys.readouterr()
+    u0 = np.zeros((horizon - 1, 7))
+    X2, F_X2, U2 = planner2.solve(u0, 100, 5, .25, 1.1, True, True, cb)
+    _check_stream(capsys.readouterr().out.strip().splitlines(), g["solves"][1]["trace"])
+    assert np.asarray(X2).shape == (400, 7) and np.asarray(X2)[:, 5].max() < 2.0 + 2e-2  # the constrained joint stays below its bound
+
+
+def test_time_sys_tutorial_and_batch(capsys):
+    from PyLQR.sim import KDLRobot
+    from PyLQR.solver import ILQRRecursive
+    from PyLQR.system import PosOrnTimePlannerSys, SpacetimeKeypoint
+    from PyLQR.utils import PythonCallbackMessage
+
+    g = golden()["cases"]["POS_ORN_TIME_SYS"]
+    dof, horizon = 7, 100
+    q0, dq0 = [0] * dof, [0] * dof
+    qMax, dqMax = np.array([np.pi] * dof) * 10, np.array([10] * dof)
+    rbt = KDLRobot(URDF, "panda_link0", "panda_tip", q0, dq0)
+    kps = [SpacetimeKeypoint(np.array(k["pos"]), np.array(k["orn"]), np.diag(k["Qdiag"]), k["ctime"], k["timestep"]) for k in g["problem"]["keypoints"]]
+    sys_ = PosOrnTimePlannerSys(rbt, kps, (np.ones(8) * 1e-5).tolist(), qMax, -qMax, dqMax, -dqMax, horizon, 1)
+    u0 = np.tile(np.array([0] * 7 + [0.01]), horizon - 1)
+    planner2 = ILQRRecursive(sys_)
+    cb = PythonCallbackMessage()
+    capsys.readouterr()
+    X2, F_X2, U2, K2, k2, cost = planner2.solve(u0.reshape((-1, 8)), 20, True, True, cb)
+    _check_stream(capsys.readouterr().out.strip().splitlines(), g["solves"][1]["trace"])
+    assert np.asarray(K2).shape == (99, 8, 8) and abs(np.asarray(X2)[-1, -1] - 5.0) < 0.2  # final time near its 5 s target
+
+    # new batched entry point: 32 instances with their own start configurations, same System
+    rng = np.random.default_rng(0)
+    q0s = rng.uniform(-0.2, 0.2, (32, 7))
+    res = planner2.solve_batch(u0.reshape((-1, 8)), 10, True, False, q0=q0s)
+    assert res.X.shape == (32, 100, 8) and res.U.shape == (32, 99, 8) and res.K.shape == (32, 99, 8, 8) and res.cost.shape == (32,)
+    assert res.cost_trace.shape == (32, 10) and np.all(res.iters == 10)
+    np.testing.assert_allclose(res.X[:, 0, :7], q0s)
+
+
+def test_constructor_errors_match_reference():
+    from PyLQR.sim import KDLRobot
+    from PyLQR.system import PosOrnKeypoint, PosOrnPlannerSys, PosOrnTimePlannerSys
+
+    rbt = KDLRobot(URDF, "panda_link0", "panda_tip", [0.0] * 7, [0.0] * 7)
+    kp1 = PosOrnKeypoint([0.5, 0, 0.3], [0, 1, 0, 0], np.eye(6), 10)
+    with pytest.raises(RuntimeError, match=r"Wrong keypoint type: got POS_ORN"):  # System.cpp:366
+        PosOrnTimePlannerSys(rbt, [kp1], [1e-5] * 8, 20, 1)
+    with pytest.raises(RuntimeError, match=r"Wrong keypoint order \(nb_deriv_\): Expecting 2 got 1"):  # System.cpp:369
+        PosOrnPlannerSys(rbt, [kp1], [1e-5] * 7, 20, 2, 0.1)

@@ -1,0 +1,99 @@
+"""Host mirror (pybind11 module PyLQR): everything that needs no GPU -- module layout, primitives, Sd utilities, keypoint
+residuals, constructor error behaviour -- checked against the oracle / the reference's documented behaviour."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from tests.helpers import GOLDEN, ROOT, orc
+
+sys.path.insert(0, os.path.join(ROOT, "ilqr_planner_amd", "pylqr"))
+
+
+@pytest.fixture(scope="module")
+def PyLQR():
+    try:
+        import PyLQR as m
+    except ImportError:
+        import __graft_entry__ as g
+
+        g.build()
+        import PyLQR as m
+    return m
+
+
+def test_module_layout_matches_reference(PyLQR):
+    # the tutorials' import lines (pylqr_planner/Tutorials/*.ipynb cell 0) must work verbatim
+    from PyLQR.sim import KDLRobot  # noqa: F401
+    from PyLQR.solver import AL_ILQR, BatchILQRCP, Constraint, ILQRRecursive  # noqa: F401
+    from PyLQR.system import PosOrnKeypoint, PosOrnPlannerSys, PosOrnTimePlannerSys, SpacetimeKeypoint  # noqa: F401
+    from PyLQR.utils import PythonCallbackMessage, primitives  # noqa: F401
+
+    assert hasattr(PyLQR.utils, "Sd") and hasattr(PyLQR.utils.Sd, "logMap")
+
+
+@pytest.mark.parametrize("kind,fn", [("rbf", "build_psi_RBF"), ("bernstein", "build_psi_bernstein"), ("unitstep", "build_psi_unitstep"),
+                                     ("sawtooth", "build_psi_sawtooth"), ("linear", "build_psi_linear")])
+def test_primitives_match_oracle(PyLQR, kind, fn):
+    for dim, K in ((99, 2), (399, 2), (50, 5), (49, 3)):
+        got = getattr(PyLQR.utils.primitives, fn)(dim, K)
+        assert isinstance(got, np.ndarray) and got.dtype == np.float64
+        np.testing.assert_allclose(got, orc.psi(kind, dim, K), rtol=0, atol=1e-15)
+
+
+def test_sd_utils_match_oracle(PyLQR):
+    import ctypes as C
+
+    rng = np.random.default_rng(0)
+    L = orc.lib()
+    Sd = PyLQR.utils.Sd
+    for _ in range(50):
+        b, y, v = rng.normal(size=4), rng.normal(size=4), rng.normal(size=4)
+        o = np.zeros(4)
+        L.orc_sd_logmap(orc._dp(b), orc._dp(y), orc._dp(o))
+        np.testing.assert_allclose(Sd.logMap(b, y), o, atol=1e-15)
+        L.orc_sd_transport(orc._dp(v), orc._dp(b / np.linalg.norm(b)), orc._dp(y / np.linalg.norm(y)), orc._dp(o))
+        np.testing.assert_allclose(Sd.transport(v, b / np.linalg.norm(b), y / np.linalg.norm(y)), o, atol=1e-13)
+        L.orc_sd_expmap(orc._dp(b), orc._dp(v), orc._dp(o))
+        np.testing.assert_allclose(Sd.expMap(b, v), o, atol=1e-15)
+        assert abs(Sd.distance(b / np.linalg.norm(b), y / np.linalg.norm(y)) - L.orc_sd_distance(orc._dp(b / np.linalg.norm(b)), orc._dp(y / np.linalg.norm(y)))) < 1e-15
+    np.testing.assert_array_equal(Sd.logMap(np.zeros(4), [1, 0, 0, 0]), np.zeros(4))  # sd.h:68-70
+    assert Sd.dquat_to_w_jac([1, 2, 3, 4]).tolist() == [[-2, 1, -4, 3], [-3, 4, 1, -2], [-4, -3, 2, 1]]
+
+
+def test_keypoint_classes(PyLQR):
+    from PyLQR.system import PosOrnKeypoint, SpacetimeKeypoint
+
+    pos, orn = [0.5, 0.1, 0.3], [0.0, 0.92387953, 0.38268343, 0.0]
+    kp = PosOrnKeypoint(pos, orn, np.diag([1, 1, 1, .1, .1, .1]), 49)
+    assert kp.get_timestep() == 49 and kp.get_precision().shape == (6, 6)
+    np.testing.assert_allclose(kp.get_state(), pos + orn)
+    np.testing.assert_array_equal(kp.diff(np.zeros(7)), np.zeros(6))  # PosOrnKeypoint.cpp:29
+    # residual against the oracle's restatement
+    seg = orc.chain_from_urdf(open(os.path.join(GOLDEN, "panda_chain.urdf")).read(), "panda_link0", "panda_tip")
+    s = orc.make_system(seg, orc.SYS_POS_ORN, 2, 100, 0.1, [1e-5] * 7,
+                        [dict(timestep=49, pos=pos, orn=orn, dpos=[.1, .2, .3], dorn=[0, .1, 0, .2], Q=np.eye(12))], [0.1] * 7, [0.2] * 7)
+    fx, _ = orc.get_fx_jac(s, np.array([0.1] * 7 + [0.2] * 7))
+    e = np.zeros(12)
+    orc.lib().orc_kp_diff(__import__("ctypes").byref(s), __import__("ctypes").byref(s.kp[0]), orc._dp(fx), orc._dp(e))
+    kp2 = PosOrnKeypoint(pos, [.1, .2, .3], orn, [0, .1, 0, .2], np.eye(12), 49)
+    np.testing.assert_allclose(kp2.diff(fx), e, atol=1e-14)
+    np.testing.assert_allclose(kp2.get_state(), pos + [.1, .2, .3] + orn + [0, .1, 0, .2])  # the reference's [p, dp, quat, dquat] layout
+    st = SpacetimeKeypoint(pos, orn, np.eye(7), 2.5, 10)
+    assert st.get_continuous_time() == 2.5
+    np.testing.assert_allclose(st.diff(np.array(list(fx[:7]) + [1.0]))[-1], 1.5)
+
+
+def test_kdlrobot_errors_and_no_cpu_fallback(PyLQR):
+    import torch
+    from PyLQR.sim import KDLRobot
+
+    urdf = os.path.join(GOLDEN, "panda_chain.urdf")
+    with pytest.raises(RuntimeError, match=r"\[KDLRobot\] Unable to build kinematic chain from nope to panda_tip"):
+        KDLRobot(urdf, "nope", "panda_tip", [0.0] * 7, [0.0] * 7)
+    with pytest.raises(RuntimeError, match="Unable to open URDF"):
+        KDLRobot("/nonexistent/model.urdf", "panda_link0", "panda_tip", [0.0] * 7, [0.0] * 7)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="only run on the GPU"):  # FK runs on the device: fail loudly, never on the CPU
+            KDLRobot(urdf, "panda_link0", "panda_tip", [0.0] * 7, [0.0] * 7)
