@@ -115,20 +115,24 @@ __global__ __launch_bounds__(256) void k_forward_tile(Bufs a, FwdArgs f) {
     const int lcur = a.cur[lb];
     const double* Xc = a.X[lcur];
     const double* Uc = a.U[lcur];
-    const double* Kp = a.K;
-    const double* Dp = a.D;
+    // per-thread load slots: address of step 0 and byte stride per timestep, resolved once (K | d | xbar | ubar regions)
+    const double* lptr[NLD];
+    size_t lstep[NLD];
+    UNR for (int j = 0; j < NLD; j++) {
+        const int c = lc0 + 16 * j;
+        const double* base = a.K;
+        int row = c, per = NK;
+        if (c >= NK + NU + NX) { base = Uc; row = c - NK - NU - NX; per = NU; }
+        else if (c >= NK + NU) { base = Xc; row = c - NK - NU; per = NX; }
+        else if (c >= NK) { base = a.D; row = c - NK; per = NU; }
+        lptr[j] = base + (size_t)row * Bp + lb;
+        lstep[j] = (size_t)per * Bp;
+    }
     auto load_step = [&](int k, double* r) {
-        UNR for (int j = 0; j < NLD; j++) {
-            const int c = lc0 + 16 * j;
-            r[j] = 0;
-            if (c < NC && k < T - 1) {
-                const double* base;
-                int row;
-                if (c < NK) { base = Kp; row = k * NK + c; }
-                else if (c < NK + NU) { base = Dp; row = k * NU + (c - NK); }
-                else if (c < NK + NU + NX) { base = Xc; row = k * NX + (c - NK - NU); }
-                else { base = Uc; row = k * NU + (c - NK - NU - NX); }
-                r[j] = base[(size_t)row * Bp + lb];
+        if (k < T - 1) {  // uniform
+            UNR for (int j = 0; j < NLD; j++) {
+                r[j] = 0;
+                if (lc0 + 16 * j < NC) r[j] = lptr[j][(size_t)k * lstep[j]];
             }
         }
     };
@@ -139,14 +143,20 @@ __global__ __launch_bounds__(256) void k_forward_tile(Bufs a, FwdArgs f) {
         }
     };
     // output stage: thread t stores component (t >> 4) + 16 j of instance t & 15
-    double* Xn = a.X[1 - lcur];
-    double* Un = a.U[1 - lcur];
+    constexpr int NST = (NO + 15) / 16;
+    double* sptr[NST];
+    size_t sstep[NST];
+    UNR for (int j = 0; j < NST; j++) {
+        const int cc = lc0 + 16 * j;
+        const bool isx = cc < NX;
+        sptr[j] = (isx ? a.X[1 - lcur] + (size_t)cc * Bp : a.U[1 - lcur] + (size_t)(cc - NX) * Bp) + lb;
+        sstep[j] = (size_t)(isx ? NX : NU) * Bp;
+    }
     auto store_step = [&](int k, int buf) {  // x_k (k <= T-1), u_k (k <= T-2)
         if (s_wr[li]) {
-            UNR for (int j = 0; j < (NO + 15) / 16; j++) {
+            UNR for (int j = 0; j < NST; j++) {
                 const int cc = lc0 + 16 * j;
-                if (cc < NX) Xn[(size_t)(k * NX + cc) * Bp + lb] = s_out[buf][cc][li];
-                else if (cc < NO && k < T - 1) Un[(size_t)(k * NU + (cc - NX)) * Bp + lb] = s_out[buf][cc][li];
+                if (cc < NX || (cc < NO && k < T - 1)) sptr[j][(size_t)k * sstep[j]] = s_out[buf][cc][li];
             }
         }
     };
