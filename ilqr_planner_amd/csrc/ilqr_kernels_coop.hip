@@ -1,0 +1,288 @@
+// ilqr_kernels_coop.hip -- wave-cooperative closed-form backward Riccati sweep (gfx950, fp64).
+//
+// Same mathematics as k_backward_si (ilqr_kernels_v2.hip): single-integrator dynamics, S = D + dt^2 P, M = S^-1,
+//   K = (M D - I)/dt,  d = -M Qu,  P' = l_xx + [D - D M D - reg (D M^2 D - D M - M D + I)]/dt^2,
+//   p' = l_x + p - (Qu + D d)/dt - reg (D M d - d)/dt
+// but mapped for a batch that is too small to fill the chip with one lane per instance (B = 4096 is 64 waves):
+// LPI lanes (32, 16 or 8) cooperate on ONE instance, 64/LPI instances per single-wave workgroup.
+//   every lane owns EPL = ceil(28/LPI) of the 28 unique entries (i >= j) of the symmetric 7x7 matrices P, S, M, M^2
+//   lanes 0..6 additionally own component l of the vectors p, x, u, Qu, d
+// The full matrix lives in LDS (rows padded to 64 B) so that any lane can read any row; the inverse is the symmetric
+// sweep operator applied to the 7 pivots in order (a_cc <- -1/a_cc, a_ic <- a_ic/a_cc, a_ij <- a_ij - a_ic a_jc/a_cc;
+// after all pivots the matrix holds -S^-1), one LDS round trip per pivot; S is SPD so no pivoting is needed.  The
+// reciprocal of the NEXT pivot is formed by every lane from two extra broadcast reads while the current update is in
+// flight, which takes the reciprocal chain off the per-pivot critical path.
+// All exchange is wave-local: LDS operations of one wave execute in order, so there is no barrier anywhere.
+#include <cstdlib>
+
+#include "ilqr_kernels.hpp"
+#include "ilqr_step.hpp"
+
+namespace ilqr {
+
+__device__ __forceinline__ double rcp_nr(double x) {  // 1/x: v_rcp_f64 + two Newton steps (no IEEE division sequence)
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    return fma(r, e, r);
+}
+#define LDS_ORDER() asm volatile("" ::: "memory")
+
+template <int MR, int LPI>
+__global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a) {
+    constexpr int N = 7, IPW = 64 / LPI, EPL = (28 + LPI - 1) / LPI;
+    constexpr int MRR = MR > 0 ? MR : 1;
+    __shared__ __attribute__((aligned(16))) double sA[IPW][N][10];  // symmetric matrix, full storage; rows padded to 80 B: row starts fall
+                                                                     // in distinct banks (20 i mod 64) and stay 16-B aligned for ds_read_b128
+    __shared__ double sV[IPW][3][8];   // 0: x   1: Qu   2: dv
+    const DevDesc& d = *a.desc;
+    const int lane = threadIdx.x, g = lane / LPI, l = lane % LPI;
+    const int b = blockIdx.x * IPW + g;
+    const int Bp = d.Bp, T = d.T;
+    const bool ok = (b < d.B) && a.active[b < d.B ? b : 0];
+    if (__ballot(ok ? 1 : 0) == 0ull) return;  // wave-uniform
+    const int bb = (b < d.B) ? b : 0;           // clamp so that every address stays valid; stores are guarded by `ok`
+
+    const bool isV = l < N;
+    const int v = isV ? l : 0;
+    const int cur = a.cur[bb];
+    const double* X = a.X[cur];
+    const double* U = a.U[cur];
+    const double dt = d.dt, idt = 1.0 / dt, idt2 = idt * idt, reg = d.reg, dt2 = dt * dt;
+    const double Rv = d.R_diag[v], Dv = Rv + reg;
+    const int lim_on = d.limits_set;
+    const double pen = d.penalty;
+    const double smax_v = d.smax[v], smin_v = d.smin[v];
+    const int lw_v = d.lw[v];
+
+    // entries owned by this lane: n = l + e*LPI (entries beyond 27 shadow entry 0 and never store)
+    bool isE[EPL], dg[EPL];
+    int ei[EPL], ej[EPL];
+    double Di[EPL], Dj[EPL], del[EPL], smax_i[EPL], smin_i[EPL];
+    int lw_i[EPL];
+    double *sAij[EPL], *sAji[EPL];
+    const double *rowI[EPL], *rowJ[EPL];
+    double *Kij[EPL], *Kji[EPL];
+    UNR for (int e = 0; e < EPL; e++) {
+        const int n = l + e * LPI;
+        isE[e] = n < 28;
+        const int le = isE[e] ? n : 0;
+        const int i = (le >= 1) + (le >= 3) + (le >= 6) + (le >= 10) + (le >= 15) + (le >= 21);
+        const int j = le - i * (i + 1) / 2;
+        ei[e] = i; ej[e] = j; dg[e] = (i == j);
+        Di[e] = d.R_diag[i] + reg; Dj[e] = d.R_diag[j] + reg; del[e] = dg[e] ? 1.0 : 0.0;
+        smax_i[e] = d.smax[i]; smin_i[e] = d.smin[i]; lw_i[e] = d.lw[i];
+        sAij[e] = &sA[g][i][j]; sAji[e] = &sA[g][j][i];
+        rowI[e] = &sA[g][i][0]; rowJ[e] = &sA[g][j][0];
+        Kij[e] = a.K + (size_t)(i * N + j) * Bp + bb + (size_t)(T - 2) * N * N * Bp;
+        Kji[e] = a.K + (size_t)(j * N + i) * Bp + bb + (size_t)(T - 2) * N * N * Bp;
+    }
+    const double* rowV = &sA[g][v][0];
+    // constraint rows (state part only: checked on the host)
+    const int m = a.m;
+    double Ai[MRR][EPL], Aj[MRR][EPL], Av[MRR], bbr[MRR], Arow[MRR][N];
+    UNR for (int r = 0; r < MRR; r++) {
+        Av[r] = bbr[r] = 0;
+        UNR for (int e = 0; e < EPL; e++) Ai[r][e] = Aj[r][e] = 0;
+        UNR for (int q = 0; q < N; q++) Arow[r][q] = 0;
+        if (MR > 0 && r < m) {
+            const double* Ar = a.conA + (size_t)r * 2 * N;
+            UNR for (int e = 0; e < EPL; e++) { Ai[r][e] = Ar[ei[e]]; Aj[r][e] = Ar[ej[e]]; }
+            Av[r] = Ar[v]; bbr[r] = a.conb[r];
+            UNR for (int q = 0; q < N; q++) Arow[r][q] = Ar[q];
+        }
+    }
+    // running pointers (decremented by one timestep per iteration: no 64-bit multiplies in the loop)
+    const ptrdiff_t Kstep = (ptrdiff_t)N * N * Bp, Vstep = (ptrdiff_t)N * Bp, Lstep = (ptrdiff_t)m * Bp;
+    double* Dv_out = a.D + (size_t)v * Bp + bb + (size_t)(T - 2) * Vstep;
+
+    int kpi = d.n_kp - 1;
+    int kp_next = (kpi >= 0) ? d.kp_t[kpi] : -1;
+    const size_t kpd_stride = (size_t)(N + N * N) * Bp;
+
+    // terminal values: P = l_xx(x_{T-1}), p = l_x(x_{T-1})
+    double P[EPL], p = 0;
+    UNR for (int e = 0; e < EPL; e++) P[e] = 0;
+    {
+        const double xv = AT(X, (T - 1) * N + v, bb);
+        if (kp_next == T - 1) {
+            const double* src = a.kpd + (size_t)kpi * kpd_stride;
+            UNR for (int e = 0; e < EPL; e++) P[e] = AT(src, N + ei[e] * N + ej[e], bb);
+            p = AT(src, v, bb);
+            kpi--;
+            kp_next = (kpi >= 0) ? d.kp_t[kpi] : -1;
+        } else if (lim_on) {
+            UNR for (int e = 0; e < EPL; e++) {
+                const double xi = AT(X, (T - 1) * N + ei[e], bb);
+                if (dg[e] && lw_i[e] != 0 && (xi > smax_i[e] || xi < smin_i[e])) P[e] = pen * pen;
+            }
+            if (lw_v != 0) {
+                if (xv > smax_v) p = -pen * (smax_v - xv);
+                else if (xv < smin_v) p = -pen * (smin_v - xv);
+            }
+        }
+    }
+    // PF-steps-ahead prefetch ring (vmcnt retires loads and stores in issue order, so a load issued only one step ahead
+    // would wait for all of the previous step's gain stores to be acknowledged)
+    constexpr int PF = 4;
+    const double* Xp = X + (size_t)v * Bp + bb + (size_t)(T - 2) * Vstep;
+    const double* Up = U + (size_t)v * Bp + bb + (size_t)(T - 2) * Vstep;
+    const double* Lp = a.lambda + bb + (size_t)(T - 2) * Lstep;
+    const double* Ip = a.Is + bb + (size_t)(T - 2) * Lstep;
+    double xr[PF], ur[PF], lr[PF][MRR], ir[PF][MRR];
+    auto fetch = [&](int slot, int kk) {  // loads of timestep kk into ring slot
+        if (kk >= 0) {
+            xr[slot] = *Xp;
+            ur[slot] = *Up;
+            UNR for (int r = 0; r < MRR; r++) {
+                lr[slot][r] = ir[slot][r] = 0;
+                if (MR > 0 && r < m) { lr[slot][r] = Lp[(size_t)r * Bp]; ir[slot][r] = Ip[(size_t)r * Bp]; }
+            }
+            Xp -= Vstep; Up -= Vstep; Lp -= Lstep; Ip -= Lstep;
+        }
+    };
+    UNR for (int q = 0; q < PF; q++) fetch(q, T - 2 - q);
+
+    for (int k0 = T - 2; k0 >= 0; k0 -= PF) {
+      UNR for (int jj = 0; jj < PF; jj++) {
+        const int k = k0 - jj;
+        if (k < 0) break;  // uniform
+        const double xv = xr[jj], uv = ur[jj];
+        double lam[MRR], Isk[MRR];
+        UNR for (int r = 0; r < MRR; r++) { lam[r] = lr[jj][r]; Isk[r] = ir[jj][r]; }
+        fetch(jj, k - PF);
+        // ---- vectors in: x, Qu = R u + dt p
+        const double Qu = Rv * uv + dt * p;
+        if (isV) { sV[g][0][v] = xv; sV[g][1][v] = Qu; }
+        // ---- S = D + dt^2 P, full storage
+        double s[EPL];
+        UNR for (int e = 0; e < EPL; e++) {
+            s[e] = dt2 * P[e] + (dg[e] ? Di[e] : 0.0);
+            *sAij[e] = s[e];
+            *sAji[e] = s[e];
+        }
+        LDS_ORDER();
+        // ---- symmetric sweeps: after the 7 pivots the matrix holds -S^-1
+        double r = rcp_nr(sA[g][0][0]);
+        UNR for (int c = 0; c < N; c++) {
+            double aic[EPL], ajc[EPL];
+            UNR for (int e = 0; e < EPL; e++) { aic[e] = rowI[e][c]; ajc[e] = rowJ[e][c]; }
+            double rn = 0;
+            if (c + 1 < N) {  // next pivot after this sweep: a_{c+1,c+1} - a_{c+1,c}^2 / a_cc
+                const double an = sA[g][c + 1][c + 1], anc = sA[g][c + 1][c];
+                rn = rcp_nr(fma(-(anc * r), anc, an));
+            }
+            LDS_ORDER();
+            UNR for (int e = 0; e < EPL; e++) {
+                const double t = aic[e] * r;
+                double val = fma(-t, ajc[e], s[e]);
+                if (ej[e] == c) val = t;               // entry (i, c), i != c : a_ic / d
+                if (ei[e] == c) val = ajc[e] * r;      // entry (c, j), j != c : a_cj / d
+                if (ei[e] == c && ej[e] == c) val = -r;
+                s[e] = val;
+                *sAij[e] = val;
+                *sAji[e] = val;
+            }
+            LDS_ORDER();
+            r = rn;
+        }
+        double M[EPL];
+        UNR for (int e = 0; e < EPL; e++) {
+            M[e] = -s[e];
+            *sAij[e] = M[e];
+            *sAji[e] = M[e];
+        }
+        LDS_ORDER();
+        // ---- M^2 entries = row_i . row_j ; vector lanes: dv = -row_v . Qu  (two partial sums each: shorter chains)
+        double m2[EPL];
+        UNR for (int e = 0; e < EPL; e++) {
+            double s0 = 0, s1 = 0;
+            UNR for (int q = 0; q < N; q += 2) s0 += rowI[e][q] * rowJ[e][q];
+            UNR for (int q = 1; q < N; q += 2) s1 += rowI[e][q] * rowJ[e][q];
+            m2[e] = s0 + s1;
+        }
+        double dv;
+        {
+            double s0 = 0, s1 = 0;
+            UNR for (int q = 0; q < N; q += 2) s0 += rowV[q] * sV[g][1][q];
+            UNR for (int q = 1; q < N; q += 2) s1 += rowV[q] * sV[g][1][q];
+            dv = -(s0 + s1);
+        }
+        if (isV) sV[g][2][v] = dv;
+        LDS_ORDER();
+        double Md;
+        {
+            double s0 = 0, s1 = 0;
+            UNR for (int q = 0; q < N; q += 2) s0 += rowV[q] * sV[g][2][q];
+            UNR for (int q = 1; q < N; q += 2) s1 += rowV[q] * sV[g][2][q];
+            Md = s0 + s1;
+        }
+        // ---- gains out
+        UNR for (int e = 0; e < EPL; e++) {
+            if (ok && isE[e]) {
+                *Kij[e] = (M[e] * Dj[e] - del[e]) * idt;
+                if (!dg[e]) *Kji[e] = (M[e] * Di[e]) * idt;
+            }
+            Kij[e] -= Kstep;
+            Kji[e] -= Kstep;
+        }
+        if (ok && isV) *Dv_out = dv;
+        Dv_out -= Vstep;
+        // ---- stage derivatives l_xx (entries), l_x (vector component)
+        double lxx[EPL], lx = 0;
+        UNR for (int e = 0; e < EPL; e++) lxx[e] = 0;
+        if (k == kp_next) {  // uniform: keypoint step, precomputed by k_kp_derivs (incl. limits)
+            const double* src = a.kpd + (size_t)kpi * kpd_stride;
+            UNR for (int e = 0; e < EPL; e++) lxx[e] = AT(src, N + ei[e] * N + ej[e], bb);
+            lx = AT(src, v, bb);
+            kpi--;
+            kp_next = (kpi >= 0) ? d.kp_t[kpi] : -1;
+        } else if (lim_on) {
+            UNR for (int e = 0; e < EPL; e++) {
+                const double xi = sV[g][0][ei[e]];
+                if (dg[e] && lw_i[e] != 0 && (xi > smax_i[e] || xi < smin_i[e])) lxx[e] = pen * pen;
+            }
+            if (lw_v != 0) {
+                if (xv > smax_v) lx = -pen * (smax_v - xv);
+                else if (xv < smin_v) lx = -pen * (smin_v - xv);
+            }
+        }
+        if (MR > 0) {
+            UNR for (int rr = 0; rr < MRR; rr++) {
+                if (rr < m) {
+                    double gr = -bbr[rr];
+                    UNR for (int q = 0; q < N; q++) gr += Arow[rr][q] * sV[g][0][q];
+                    UNR for (int e = 0; e < EPL; e++) lxx[e] += Ai[rr][e] * Isk[rr] * Aj[rr][e];
+                    lx += Av[rr] * (lam[rr] + Isk[rr] * gr);
+                }
+            }
+        }
+        // ---- P', p'
+        UNR for (int e = 0; e < EPL; e++) {
+            const double t1 = del[e] * Di[e] - Di[e] * M[e] * Dj[e] - reg * (Di[e] * m2[e] * Dj[e] - Di[e] * M[e] - M[e] * Dj[e] + del[e]);
+            P[e] = lxx[e] + t1 * idt2;
+        }
+        p = lx + p - (Qu + Dv * dv) * idt - reg * (Dv * Md - dv) * idt;
+        LDS_ORDER();
+      }
+    }
+}
+
+template <int LPI>
+static void launch_coop(bool al, const Bufs& a, int B, hipStream_t st) {
+    constexpr int IPW = 64 / LPI;
+    const dim3 grid((B + IPW - 1) / IPW), block(64);
+    if (!al) hipLaunchKernelGGL((k_backward_si_coop<0, LPI>), grid, block, 0, st, a);
+    else if (a.m <= 1) hipLaunchKernelGGL((k_backward_si_coop<1, LPI>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((k_backward_si_coop<4, LPI>), grid, block, 0, st, a);
+}
+
+void launch_backward_si_coop(bool al, const Bufs& a, int B, hipStream_t st) {
+    static const int lpi = std::getenv("ILQR_BWD_LPI") ? std::atoi(std::getenv("ILQR_BWD_LPI")) : 32;  // lanes per instance
+    if (lpi == 32) launch_coop<32>(al, a, B, st);
+    else if (lpi == 8) launch_coop<8>(al, a, B, st);
+    else launch_coop<16>(al, a, B, st);
+}
+
+}  // namespace ilqr

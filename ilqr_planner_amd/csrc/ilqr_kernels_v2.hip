@@ -27,6 +27,7 @@
 // Everything a loop needs from the shared descriptor is copied into registers before the loop: the compiler cannot
 // prove that the trajectory stores do not alias the descriptor and would otherwise re-issue scalar loads every step.
 #include <cstdlib>
+#include <cstring>
 
 #include "ilqr_kernels.hpp"
 #include "ilqr_step.hpp"
@@ -564,6 +565,8 @@ bool backward_si_supported(int kind, int nd, bool al, int m, int per_step, bool 
 
 void launch_solver_v2(int kind, int nd, int which, bool al, const Bufs& a, int B, int T, hipStream_t st, const FwdArgs& f) {
     if (which == KER_BACKWARD_SI) {
+        static const bool lane_path = std::getenv("ILQR_BWD") && !std::strcmp(std::getenv("ILQR_BWD"), "lane");
+        if (!lane_path) { launch_backward_si_coop(al, a, B, st); return; }  // default: 32 lanes per instance
         static const int bs = std::getenv("ILQR_BWD_BLOCK") ? std::atoi(std::getenv("ILQR_BWD_BLOCK")) : 64;  // lanes used per wave (experiment)
         const dim3 grid((B + bs - 1) / bs), block(bs);
         if (!al) hipLaunchKernelGGL((k_backward_si<0>), grid, block, 0, st, a);
