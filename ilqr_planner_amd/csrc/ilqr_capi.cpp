@@ -285,6 +285,10 @@ extern "C" int ilqr_problem_create(ilqr_ctx* c, const ilqr_problem_desc* d, int 
     p->desc = *d;
     p->B = batch;
     p->Bp = (batch + 63) / 64 * 64;
+    // Row stride of every [row][Bp] buffer is Bp*8 bytes.  A power-of-two stride (Bp = 4096 -> 32 KiB) maps the 49 rows
+    // of a K block onto the same L2 sets / HBM channel; one extra 64-instance pad column breaks the alignment.
+    if (const char* e = std::getenv("ILQR_BP_PAD")) { p->Bp += 64 * std::atoi(e); }
+    else if (p->Bp % 512 == 0) p->Bp += 64;
     p->T = d->horizon;
     if (ilqr_dims_of(d, &p->dims) || lower_desc(c, *d, p->B, p->Bp, p->hdesc)) { delete p; return 1; }
     const int T = p->T, NX = p->dims.n_x, NU = p->dims.n_u, NF = p->dims.n_f, Bp = p->Bp;
@@ -464,6 +468,9 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
     if (line_search) { double al_ = 1.0; while (al_ > p->desc.alpha_floor && n_alpha < 64) { al_ *= 0.5; n_alpha++; } }
     const int path = path_choice();
     const bool fwd_tile = (path != 1) && n_alpha <= 16;
+    const char* fwd_env = std::getenv("ILQR_FWD");
+    const bool fwd_rows = fwd_tile && forward_rows_supported(kind, nd, n_alpha) && !(fwd_env && !std::strcmp(fwd_env, "tile"));
+    const bool fwd_lin = fwd_rows && !(fwd_env && !std::strcmp(fwd_env, "rows"));  // linear line search (PosOrn systems)
     const bool bwd_si = (path == 2) && backward_si_supported(kind, nd, al, p->bufs.m, p->bufs.per_step, p->con_state_only);
     FwdArgs f;
     std::memset(&f, 0, sizeof(f));
@@ -491,9 +498,15 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
         if (fwd_tile) {
             {
                 ProfScope ps(c, ILQR_PROF_FORWARD);
-                launch_solver_v2(kind, nd, KER_FWD_SPEC, al, p->bufs, p->B, p->T, c->stream, f);
+                if (fwd_lin) launch_forward_lin(nd, KER_FWD_SPEC, p->bufs, p->B, p->T, c->stream, f);
+                else if (fwd_rows) launch_forward_rows(nd, KER_FWD_SPEC, p->bufs, p->B, c->stream, f);
+                else launch_solver_v2(kind, nd, KER_FWD_SPEC, al, p->bufs, p->B, p->T, c->stream, f);
             }
-            if (line_search) {
+            if (fwd_rows) {  // the cost pass writes no trajectory: the winner is always re-rolled
+                ProfScope ps(c, ILQR_PROF_APPLY);
+                if (fwd_lin) launch_forward_lin(nd, KER_FWD_APPLY, p->bufs, p->B, p->T, c->stream, f);
+                else launch_forward_rows(nd, KER_FWD_APPLY, p->bufs, p->B, c->stream, f);
+            } else if (line_search) {
                 ProfScope ps(c, ILQR_PROF_APPLY);
                 launch_solver_v2(kind, nd, KER_FWD_APPLY, al, p->bufs, p->B, p->T, c->stream, f);
             }

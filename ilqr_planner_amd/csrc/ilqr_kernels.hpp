@@ -56,6 +56,9 @@ void launch_solver(int kind, int nd, int which, bool al, const Bufs& a, int B, h
 bool backward_si_supported(int kind, int nd, bool al, int m, int per_step, bool con_state_only);
 void launch_solver_v2(int kind, int nd, int which, bool al, const Bufs& a, int B, int T, hipStream_t st, const FwdArgs& f);
 void launch_backward_si_coop(bool al, const Bufs& a, int B, hipStream_t st);
+bool forward_rows_supported(int kind, int nd, int n_alpha);
+void launch_forward_rows(int nd, int which, const Bufs& a, int B, hipStream_t st, const FwdArgs& f);
+void launch_forward_lin(int nd, int which, const Bufs& a, int B, int T, hipStream_t st, const FwdArgs& f);
 void launch_fx_all(int kind, int nd, const Bufs& a, int B, int T, double* out, hipStream_t st);
 void launch_to_soa(const double* src, double* dst, int B, int Bp, int rows, hipStream_t st);
 void launch_from_soa(const double* src, double* dst, int B, int Bp, int rows, hipStream_t st);
