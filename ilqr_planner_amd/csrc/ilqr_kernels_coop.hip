@@ -38,7 +38,7 @@ __global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a) {
     __shared__ double sV[IPW][3][8];   // 0: x   1: Qu   2: dv
     const DevDesc& d = *a.desc;
     const int lane = threadIdx.x, g = lane / LPI, l = lane % LPI;
-    const int b = blockIdx.x * IPW + g;
+    const int b = xcd_tile() * IPW + g;
     const int Bp = d.Bp, T = d.T;
     const bool ok = (b < d.B) && a.active[b < d.B ? b : 0];
     if (__ballot(ok ? 1 : 0) == 0ull) return;  // wave-uniform
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a) {
 template <int LPI>
 static void launch_coop(bool al, const Bufs& a, int B, hipStream_t st) {
     constexpr int IPW = 64 / LPI;
-    const dim3 grid((B + IPW - 1) / IPW), block(64);
+    const dim3 grid(grid_x8((B + IPW - 1) / IPW)), block(64);
     if (!al) hipLaunchKernelGGL((k_backward_si_coop<0, LPI>), grid, block, 0, st, a);
     else if (a.m <= 1) hipLaunchKernelGGL((k_backward_si_coop<1, LPI>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((k_backward_si_coop<4, LPI>), grid, block, 0, st, a);

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(64) void k_forward_rows(Bufs a, FwdArgs f) {
 
     const DevDesc& d = *a.desc;
     const int lane = threadIdx.x, g = lane >> 3, r0 = lane & 7;
-    const int b = blockIdx.x * 8 + g;
+    const int b = xcd_tile() * 8 + g;
     const int Bp = d.Bp, T = d.T, B = d.B;
     const bool inst_ok = (b < B) && (APPLY ? (a.pend[b < B ? b : 0] > 0) : (a.active[b < B ? b : 0] != 0));
     if (__ballot(inst_ok ? 1 : 0) == 0ull) return;  // wave-uniform
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(64) void k_forward_lin(Bufs a, FwdArgs f) {
     constexpr int NXP = (NX + 1) & ~1;
     constexpr int DXS = NXP + 2;                  // per-instance stride (doubles) of the dx row, +16 B bank spread
     constexpr int NLD = NX + 2 + ND;
-    constexpr int PF = 4;
+    constexpr int PF = 4;                         // timesteps in flight; PF * NLD loads must stay below the 6-bit vmcnt (63)
     __shared__ __attribute__((aligned(16))) double sDX[8 * DXS];
     __shared__ __attribute__((aligned(16))) double sXB[8][NXP + 2];
     __shared__ __attribute__((aligned(16))) double sUB[8][10];
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(64) void k_forward_lin(Bufs a, FwdArgs f) {
 
     const DevDesc& d = *a.desc;
     const int lane = threadIdx.x, g = lane >> 3, r0 = lane & 7;
-    const int b = blockIdx.x * 8 + g;
+    const int b = xcd_tile() * 8 + g;
     const int Bp = d.Bp, T = d.T, B = d.B;
     const bool inst_ok = (b < B) && (a.active[b < B ? b : 0] != 0);
     if (__ballot(inst_ok ? 1 : 0) == 0ull) return;  // wave-uniform
@@ -310,14 +310,14 @@ __global__ __launch_bounds__(64) void k_forward_lin(Bufs a, FwdArgs f) {
     double* oX = a.X[1 - cur] + (size_t)r * Bp + bb;
     double* oU = a.U[1 - cur] + (size_t)r * Bp + bb;
 
-    double ring[PF][NLD];
+    constexpr int NS = PF + 1;  // ring slots: the slot consumed in step k-1 receives step k+PF-1 ... no register copies, distance PF
+    double ring[NS][NLD];
     auto fetch = [&](int slot, int k) {  // unconditional (see k_forward_rows); pointers stop at the last timestep
         UNR for (int jx = 0; jx < NX; jx++) ring[slot][jx] = pK[(size_t)jx * Bp];
         ring[slot][NX] = *pD;
         UNR for (int q = 0; q < ND; q++) ring[slot][NX + 1 + q] = pX[(size_t)(q * DOF) * Bp];
         ring[slot][NX + 1 + ND] = *pU;
-        const size_t adv = (k < T - 2) ? 1 : 0;
-        pK += adv * sK_; pD += adv * sU_; pX += adv * sX_; pU += adv * sU_;
+        if (k < T - 2) { pK += sK_; pD += sU_; pX += sX_; pU += sU_; }  // uniform; no load inside the branch
     };
     UNR for (int q = 0; q < PF; q++) fetch(q, q);
     double xT[ND];  // xbar_{T-1} of this lane's coordinates (terminal step)
@@ -353,16 +353,15 @@ __global__ __launch_bounds__(64) void k_forward_lin(Bufs a, FwdArgs f) {
     };
 
     const int nsteps = T - 1;
-    for (int k0 = 0; k0 < nsteps; k0 += PF) {
-        UNR for (int jj = 0; jj < PF; jj++) {
+    for (int k0 = 0; k0 < nsteps; k0 += NS) {
+        UNR for (int jj = 0; jj < NS; jj++) {
             const int k = k0 + jj;
             if (k >= nsteps) break;  // uniform
-            double Kr[NX];
-            UNR for (int jx = 0; jx < NX; jx++) Kr[jx] = ring[jj][jx];
+            fetch((jj + PF) % NS, k + PF);  // into the slot freed by the previous step
+            const double* Kr = ring[jj];
             const double dr = ring[jj][NX], ub = ring[jj][NX + 1 + ND];
             double xb[ND];
             UNR for (int q = 0; q < ND; q++) xb[q] = ring[jj][NX + 1 + q];
-            fetch(jj, k + PF);
             // ---- all-gather of dx
             if (act) {
                 myDX[r] = dxq;
@@ -511,7 +510,7 @@ __global__ void k_flip(Bufs a) {
 template <class S>
 static void launch_lin_sys(const Bufs& a, int B, int T, hipStream_t st, const FwdArgs& f, int which) {
     if (which == KER_FWD_SPEC) {
-        const dim3 grid((B + 7) / 8), block(64);
+        const dim3 grid(grid_x8((B + 7) / 8)), block(64);
         if (f.n_alpha <= 1) hipLaunchKernelGGL((k_forward_lin<S, 1>), grid, block, 0, st, a, f);
         else if (f.n_alpha <= 11) hipLaunchKernelGGL((k_forward_lin<S, 11>), grid, block, 0, st, a, f);
         else hipLaunchKernelGGL((k_forward_lin<S, 16>), grid, block, 0, st, a, f);
@@ -528,7 +527,7 @@ void launch_forward_lin(int nd, int which, const Bufs& a, int B, int T, hipStrea
 
 template <class S>
 static void launch_rows_sys(int which, const Bufs& a, int B, hipStream_t st, const FwdArgs& f) {
-    const dim3 grid((B + 7) / 8), block(64);
+    const dim3 grid(grid_x8((B + 7) / 8)), block(64);
     if (which == KER_FWD_APPLY) {
         hipLaunchKernelGGL((k_forward_rows<S, 1, true>), grid, block, 0, st, a, f);
     } else if (f.n_alpha <= 1) {

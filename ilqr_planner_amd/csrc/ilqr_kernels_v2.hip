@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void k_forward_tile(Bufs a, FwdArgs f) {
 
     const DevDesc& d = *a.desc;
     const int tid = threadIdx.x, il = tid >> 4, ai = tid & 15;
-    const int b0 = blockIdx.x * 16, b = b0 + il;
+    const int b0 = xcd_tile() * 16, b = b0 + il;
     const int Bp = d.Bp, T = d.T, B = d.B;
 
     // SPEC: lane `ai` tries alpha = 2^-ai; the lane whose index equals the instance's PREDICTED winner (the winner of
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(64) void k_backward_si(Bufs a) {
 
 template <class S>
 static void launch_v2_kernel(int which, const Bufs& a, int B, int T, hipStream_t st, const FwdArgs& f) {
-    const dim3 gridT((B + 15) / 16), blockT(256);
+    const dim3 gridT(grid_x8((B + 15) / 16)), blockT(256);
     switch (which) {
         case KER_FWD_SPEC:
             hipLaunchKernelGGL((k_forward_tile<S, false>), gridT, blockT, 0, st, a, f);

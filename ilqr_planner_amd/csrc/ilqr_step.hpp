@@ -6,6 +6,16 @@
 namespace ilqr {
 
 #define UNR _Pragma("unroll")
+
+// XCD-aware tile index.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an XCD and its L2), so
+// with tile = blockIdx consecutive tiles -- whose 16..64-byte row segments share 128-byte lines -- would land on 8 different
+// L2s and every line would be fetched (or partially written back) once per XCD.  Grids are launched with a multiple of 8
+// blocks; this maps the blocks of one XCD onto a contiguous range of tiles.  Placement affects speed only.
+__device__ __forceinline__ int xcd_tile() {
+    const int per = (int)gridDim.x >> 3;
+    return ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+}
+static inline unsigned grid_x8(unsigned tiles) { return (tiles + 7u) / 8u * 8u; }
 #define AT(buf, row, b) (buf)[(size_t)(row) * (size_t)Bp + (size_t)(b)]
 
 // ------------------------------------------------------------------------------------------------ helpers
