@@ -125,7 +125,8 @@ def main():
     for _ in range(args.warmup):
         step()
     ctx.profile_reset()
-    ctx.profile(True)
+    if not os.environ.get("ILQR_BENCH_NOPROF"):
+        ctx.profile(True)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):

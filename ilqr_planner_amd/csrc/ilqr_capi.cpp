@@ -113,7 +113,7 @@ extern "C" void ilqr_ctx_destroy(ilqr_ctx* c) {
     (void)hipSetDevice(c->device);
     while (!c->problems.empty()) ilqr_problem_destroy(c->problems.back());  // handles held by the caller become invalid
     (void)hipStreamSynchronize(c->stream);
-    for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto& p : c->pending) (void)hipEventDestroy(p.a);
     for (auto e : c->pool) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -145,37 +145,30 @@ static hipEvent_t ev_get(ilqr_ctx* c) {
     (void)hipEventCreate(&e);
     return e;
 }
+// One event is recorded in FRONT of every kernel launch (and one behind the last launch of a solve): the interval between two
+// consecutive marks is charged to the kernel that the first one precedes.  Half the events of a start/stop pair per kernel.
 static void prof_collect(ilqr_ctx* c) {
     if (c->pending.empty()) return;
     (void)hipStreamSynchronize(c->stream);
-    for (auto& p : c->pending) {
+    for (size_t i = 0; i + 1 < c->pending.size(); i++) {
+        const auto& p = c->pending[i];
         float ms = 0;
-        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+        if (p.which >= 0 && hipEventElapsedTime(&ms, p.a, c->pending[i + 1].a) == hipSuccess) {
             c->prof_ms[p.which] += ms;
             c->prof_n[p.which] += 1;
         }
-        c->pool.push_back(p.a);
-        c->pool.push_back(p.b);
     }
+    for (auto& p : c->pending) c->pool.push_back(p.a);
     c->pending.clear();
 }
-struct ProfScope {  // brackets ONE kernel launch with events on the launch stream
-    ilqr_ctx* c;
-    hipEvent_t a = nullptr, b = nullptr;
-    int which;
-    ProfScope(ilqr_ctx* c_, int w) : c(c_), which(w) {
-        if (c->profile) {
-            a = ev_get(c);
-            b = ev_get(c);
-            (void)hipEventRecord(a, c->stream);
-        }
-    }
-    ~ProfScope() {
-        if (c->profile) {
-            (void)hipEventRecord(b, c->stream);
-            c->pending.push_back({a, b, which});
-        }
-    }
+static void prof_mark(ilqr_ctx* c, int which) {  // which < 0: end mark (closes the previous interval, charges nothing itself)
+    if (!c->profile) return;
+    hipEvent_t e = ev_get(c);
+    (void)hipEventRecord(e, c->stream);
+    c->pending.push_back({e, nullptr, which});
+}
+struct ProfScope {  // marks the launch that follows; the interval is closed by the next mark
+    ProfScope(ilqr_ctx* c, int w) { prof_mark(c, w); }
 };
 
 extern "C" int ilqr_profile_enable(ilqr_ctx* c, int on) {
@@ -520,6 +513,7 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
         }
         HIPCHK(c, hipGetLastError());
     }
+    prof_mark(c, -1);
     return 0;
 }
 
@@ -608,6 +602,7 @@ extern "C" int ilqr_problem_get_fX(ilqr_problem* p, double* fX) {
         ProfScope ps(c, ILQR_PROF_OTHER);
         launch_fx_all(p->desc.kind, p->desc.nb_deriv, p->bufs, p->B, p->T, p->staging, c->stream);
     }
+    prof_mark(c, -1);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(fX, p->staging, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
