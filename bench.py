@@ -154,9 +154,11 @@ def main():
         frac_apply = float(np.mean(at < 1.0)) if at is not None else 0.0
         v1 = os.environ.get("ILQR_HIP_PATH") == "v1"
         kern = {}
-        # v2: the speculative pass reads K,d,x,u once and writes the alpha=1 trajectory once, whatever the trial count;
-        # v1: one full read+write per sequential trial
-        for name, byts in (("backward", bwd_bytes), ("forward", fwd_bytes * (trials if v1 else 1.0)), ("apply", fwd_bytes * frac_apply)):
+        # algorithmic bytes per launch.  backward: read x,u (+lambda,I) ; write K,d.  forward: v1 = one full read+write per
+        # sequential trial; v2 = ONE pass over K,d,x,u (+ write of x(1),u(1)) whatever the number of trials.  "apply" is the
+        # elementwise blend of the winner (read xbar,ubar,x(1),u(1); write x,u) for the instance-iterations with alpha != 1.
+        blend_bytes = 8 * 3 * (nx + nu) * (cfg["T"] - 1) * B * frac_apply
+        for name, byts in (("backward", bwd_bytes), ("forward", fwd_bytes * (trials if v1 else 1.0)), ("apply", blend_bytes)):
             ms, n = prof[name]
             if n:
                 avg = ms / n
