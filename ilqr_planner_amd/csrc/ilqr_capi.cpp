@@ -292,8 +292,7 @@ extern "C" int ilqr_problem_create(ilqr_ctx* c, const ilqr_problem_desc* d, int 
     double *q0, *dq0, *U0, *tg;
     for (int i = 0; i < 2; i++) { rc |= dalloc(p, &b.X[i], (size_t)T * NX * Bp); rc |= dalloc(p, &b.U[i], (size_t)(T - 1) * NU * Bp); }
     rc |= dalloc(p, &U0, (size_t)(T - 1) * NU * Bp);
-    rc |= dalloc(p, &b.K, (size_t)(T - 1) * NU * NX * Bp);
-    rc |= dalloc(p, &b.D, (size_t)(T - 1) * NU * Bp);
+    rc |= dalloc(p, &b.KD, (size_t)(T - 1) * Bp * NU * kd_rowp(NX));
     rc |= dalloc(p, &q0, (size_t)DOF * Bp);
     rc |= dalloc(p, &dq0, (size_t)DOF * Bp);
     rc |= dalloc(p, &tg, (size_t)(d->n_kp > 0 ? d->n_kp : 1) * NF * Bp);
@@ -563,8 +562,22 @@ extern "C" int ilqr_problem_get_X(ilqr_problem* p, double* X) { return p ? downl
 extern "C" int ilqr_problem_get_U(ilqr_problem* p, double* U) { return p ? download(p, GET_CUR, p->bufs.U[0], p->bufs.U[1], U, false, (p->T - 1) * p->dims.n_u) : 1; }
 extern "C" int ilqr_problem_get_X_dev(ilqr_problem* p, double* X) { return p ? download(p, GET_CUR, p->bufs.X[0], p->bufs.X[1], X, true, p->T * p->dims.n_x) : 1; }
 extern "C" int ilqr_problem_get_U_dev(ilqr_problem* p, double* U) { return p ? download(p, GET_CUR, p->bufs.U[0], p->bufs.U[1], U, true, (p->T - 1) * p->dims.n_u) : 1; }
-extern "C" int ilqr_problem_get_K(ilqr_problem* p, double* K) { return p ? download(p, GET_PLAIN, p->bufs.K, nullptr, K, false, (p->T - 1) * p->dims.n_u * p->dims.n_x) : 1; }
-extern "C" int ilqr_problem_get_d(ilqr_problem* p, double* d) { return p ? download(p, GET_SCALED, p->bufs.D, nullptr, d, false, (p->T - 1) * p->dims.n_u) : 1; }
+static int get_gains(ilqr_problem* p, double* K, double* d) {
+    if (!p) return 1;
+    ilqr_ctx* c = p->ctx;
+    double* dst = K ? K : d;
+    if (!dst) return fail(c, "null output pointer");
+    const int T1 = p->T - 1, nu = p->dims.n_u, nx = p->dims.n_x;
+    const size_t n = (size_t)p->B * T1 * nu * (K ? nx : 1);
+    if (ensure_staging(p, n)) return 1;
+    launch_get_gains(p->bufs.KD, p->bufs.alpha, p->bufs.iters, K ? p->staging : nullptr, K ? nullptr : p->staging, p->B, p->Bp, T1, nu, nx, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(dst, p->staging, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+extern "C" int ilqr_problem_get_K(ilqr_problem* p, double* K) { return get_gains(p, K, nullptr); }
+extern "C" int ilqr_problem_get_d(ilqr_problem* p, double* d) { return get_gains(p, nullptr, d); }
 extern "C" int ilqr_problem_get_cost(ilqr_problem* p, double* cost) { return p ? download(p, GET_PLAIN, p->bufs.cost, nullptr, cost, false, 1) : 1; }
 extern "C" int ilqr_problem_get_cost_dev(ilqr_problem* p, double* cost) { return p ? download(p, GET_PLAIN, p->bufs.cost, nullptr, cost, true, 1) : 1; }
 extern "C" int ilqr_problem_get_alpha(ilqr_problem* p, double* alpha) { return p ? download(p, GET_PLAIN, p->bufs.alpha, nullptr, alpha, false, 1) : 1; }

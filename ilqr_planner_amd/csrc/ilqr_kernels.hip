@@ -198,12 +198,12 @@ __global__ __launch_bounds__(64) void k_backward(Bufs a) {
                 double s = 0;
                 UNR for (int l = 0; l < NU; l++) s += (-1 * Qi[i][l]) * Qux[l][j];
                 Kk[i][j] = s;
-                AT(a.K, k * NU * NX + i * NX + j, b) = s;
+                KD_REC(a.KD, Bp, NU * kd_rowp(NX), k, b)[i * kd_rowp(NX) + j] = s;
             }
             double s = 0;
             UNR for (int l = 0; l < NU; l++) s += (-1 * Qi[i][l]) * Qu[l];
             dk[i] = s;
-            AT(a.D, k * NU + i, b) = s;
+            KD_REC(a.KD, Bp, NU * kd_rowp(NX), k, b)[i * kd_rowp(NX) + NX] = s;
         }
         // P = Qxx + K'QuuK + K'Qux + QxuK ; p = Qx + K'Quu d + K'Qu + Qxu d   (un-regularised Quu)
         double KtQuu[NX][NU];
@@ -265,8 +265,8 @@ __global__ __launch_bounds__(64) void k_forward(Bufs a, int it, int line_search,
             double n2 = 0;
             UNR for (int i = 0; i < NU; i++) {
                 double s = 0;
-                UNR for (int j = 0; j < NX; j++) s += AT(a.K, k * NU * NX + i * NX + j, b) * dx[j];
-                double du = s + alpha * AT(a.D, k * NU + i, b);
+                UNR for (int j = 0; j < NX; j++) s += KD_REC(a.KD, Bp, NU * kd_rowp(NX), k, b)[i * kd_rowp(NX) + j] * dx[j];
+                double du = s + alpha * KD_REC(a.KD, Bp, NU * kd_rowp(NX), k, b)[i * kd_rowp(NX) + NX];
                 n2 += du * du;
                 u[i] = AT(U, k * NU + i, b) + du;
             }
@@ -348,6 +348,21 @@ __global__ void k_from_soa_scaled(const double* __restrict__ src, const double* 
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     const int r = blockIdx.y;
     if (b < B) dst[(size_t)b * rows + r] = (iters[b] > 0 ? alpha[b] : 1.0) * src[(size_t)r * Bp + b];
+}
+
+// gains in the reference's layout: K[B][T-1][NU][NX], d[B][T-1][NU] scaled by the accepted alpha (ILQRRecursive.cpp:128,144,162)
+__global__ void k_get_gains(const double* __restrict__ kd, const double* __restrict__ alpha, const int* __restrict__ iters,
+                            double* __restrict__ K_out, double* __restrict__ d_out, int B, int Bp, int T1, int nu, int nx) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+    if (b >= B) return;
+    const int rowp = kd_rowp(nx), rs = nu * rowp;
+    const double* rec = KD_REC(kd, Bp, rs, k, b);
+    const double sc = (iters[b] > 0) ? alpha[b] : 1.0;
+    for (int i = 0; i < nu; i++) {
+        if (K_out)
+            for (int j = 0; j < nx; j++) K_out[(((size_t)b * T1 + k) * nu + i) * nx + j] = rec[i * rowp + j];
+        if (d_out) d_out[((size_t)b * T1 + k) * nu + i] = sc * rec[i * rowp + nx];
+    }
 }
 
 // f(X) for every (instance, timestep): one lane per pair (tuple<1> of ILQRRecursive::solve)
@@ -432,6 +447,10 @@ void launch_from_soa_cur(const double* s0, const double* s1, const int* cur, dou
 }
 void launch_from_soa_scaled(const double* src, const double* alpha, const int* iters, double* dst, int B, int Bp, int rows, hipStream_t st) {
     hipLaunchKernelGGL(k_from_soa_scaled, dim3((B + 255) / 256, rows), dim3(256), 0, st, src, alpha, iters, dst, B, Bp, rows);
+}
+void launch_get_gains(const double* kd, const double* alpha, const int* iters, double* K_out, double* d_out, int B, int Bp, int T1, int nu, int nx,
+                       hipStream_t st) {
+    hipLaunchKernelGGL(k_get_gains, dim3((B + 63) / 64, T1), dim3(64), 0, st, kd, alpha, iters, K_out, d_out, B, Bp, T1, nu, nx);
 }
 void launch_fk_batch(const DevDesc* dd, int n, const double* q, double* pos, double* quat, double* jac, hipStream_t st) {
     hipLaunchKernelGGL(k_fk_batch, dim3((n + 63) / 64), dim3(64), 0, st, dd, n, q, pos, quat, jac);

@@ -12,8 +12,9 @@ struct Bufs {
     double* X[2];  // [T][NX][Bp]   double-buffered; cur[b] says which one holds instance b's accepted trajectory
     double* U[2];  // [T-1][NU][Bp]
     const double* U0;  // [T-1][NU][Bp]
-    double* K;     // [T-1][NU*NX][Bp]
-    double* D;     // [T-1][NU][Bp]
+    double* KD;    // gains, one record per (timestep, instance): [T-1][Bp][NU][ROWP], row i = { K_k[i][0..NX-1], d_k[i], pad };
+                   // ROWP = NX+1 rounded up to even, so rows are 16-byte aligned: the cooperative kernels read a gain row
+                   // with 16-byte loads and the sweep writes an instance's block as one contiguous 448-byte run
     const double* q0;   // [DOF][Bp]
     const double* dq0;  // [DOF][Bp]
     const double* kp_tg;  // [n_kp][NF][Bp]
@@ -35,6 +36,9 @@ struct Bufs {
     double* lambda;      // [T-1][m][Bp]
     double* Is;          // [T-1][m][Bp]  penalty * active-set mask at rollout time
 };
+
+constexpr int kd_rowp(int nx) { return (nx + 2) & ~1; }
+#define KD_REC(kd, Bp, RS, k, b) ((kd) + ((size_t)(k) * (size_t)(Bp) + (size_t)(b)) * (size_t)(RS))
 
 struct FwdArgs {
     int it, line_search, early_stop, do_update, nb_iter;
@@ -64,6 +68,7 @@ void launch_to_soa(const double* src, double* dst, int B, int Bp, int rows, hipS
 void launch_from_soa(const double* src, double* dst, int B, int Bp, int rows, hipStream_t st);
 void launch_from_soa_cur(const double* s0, const double* s1, const int* cur, double* dst, int B, int Bp, int rows, hipStream_t st);
 void launch_from_soa_scaled(const double* src, const double* alpha, const int* iters, double* dst, int B, int Bp, int rows, hipStream_t st);
+void launch_get_gains(const double* kd, const double* alpha, const int* iters, double* K_out, double* d_out, int B, int Bp, int T1, int nu, int nx, hipStream_t st);
 void launch_fk_batch(const DevDesc* dd, int n, const double* q, double* pos, double* quat, double* jac, hipStream_t st);
 
 }  // namespace ilqr

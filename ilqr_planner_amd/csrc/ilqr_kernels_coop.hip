@@ -33,6 +33,7 @@ template <int MR, int LPI>
 __global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a) {
     constexpr int N = 7, IPW = 64 / LPI, EPL = (28 + LPI - 1) / LPI;
     constexpr int MRR = MR > 0 ? MR : 1;
+    constexpr int ROWP = kd_rowp(N), RS = N * ROWP;
     __shared__ __attribute__((aligned(16))) double sA[IPW][N][10];  // symmetric matrix, full storage; rows padded to 80 B: row starts fall
                                                                      // in distinct banks (20 i mod 64) and stay 16-B aligned for ds_read_b128
     __shared__ double sV[IPW][3][8];   // 0: x   1: Qu   2: dv
@@ -75,8 +76,8 @@ __global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a) {
         smax_i[e] = d.smax[i]; smin_i[e] = d.smin[i]; lw_i[e] = d.lw[i];
         sAij[e] = &sA[g][i][j]; sAji[e] = &sA[g][j][i];
         rowI[e] = &sA[g][i][0]; rowJ[e] = &sA[g][j][0];
-        Kij[e] = a.K + (size_t)(i * N + j) * Bp + bb + (size_t)(T - 2) * N * N * Bp;
-        Kji[e] = a.K + (size_t)(j * N + i) * Bp + bb + (size_t)(T - 2) * N * N * Bp;
+        Kij[e] = KD_REC(a.KD, Bp, RS, T - 2, bb) + i * ROWP + j;
+        Kji[e] = KD_REC(a.KD, Bp, RS, T - 2, bb) + j * ROWP + i;
     }
     const double* rowV = &sA[g][v][0];
     // constraint rows (state part only: checked on the host)
@@ -94,8 +95,8 @@ __global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a) {
         }
     }
     // running pointers (decremented by one timestep per iteration: no 64-bit multiplies in the loop)
-    const ptrdiff_t Kstep = (ptrdiff_t)N * N * Bp, Vstep = (ptrdiff_t)N * Bp, Lstep = (ptrdiff_t)m * Bp;
-    double* Dv_out = a.D + (size_t)v * Bp + bb + (size_t)(T - 2) * Vstep;
+    const ptrdiff_t Kstep = (ptrdiff_t)Bp * RS, Vstep = (ptrdiff_t)N * Bp, Lstep = (ptrdiff_t)m * Bp;
+    double* Dv_out = KD_REC(a.KD, Bp, RS, T - 2, bb) + v * ROWP + N;
 
     int kpi = d.n_kp - 1;
     int kp_next = (kpi >= 0) ? d.kp_t[kpi] : -1;
@@ -131,27 +132,30 @@ __global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a) {
     const double* Lp = a.lambda + bb + (size_t)(T - 2) * Lstep;
     const double* Ip = a.Is + bb + (size_t)(T - 2) * Lstep;
     double xr[PF], ur[PF], lr[PF][MRR], ir[PF][MRR];
-    auto fetch = [&](int slot, int kk) {  // loads of timestep kk into ring slot
-        if (kk >= 0) {
-            xr[slot] = *Xp;
-            ur[slot] = *Up;
-            UNR for (int r = 0; r < MRR; r++) {
-                lr[slot][r] = ir[slot][r] = 0;
-                if (MR > 0 && r < m) { lr[slot][r] = Lp[(size_t)r * Bp]; ir[slot][r] = Ip[(size_t)r * Bp]; }
-            }
-            Xp -= Vstep; Up -= Vstep; Lp -= Lstep; Ip -= Lstep;
+    // Every load of the ring is unconditional and the unrolled group has no early exit: a CFG path that skips a fetch makes
+    // the waitcnt pass fall back to vmcnt(0), which also waits for the previous step's gain stores.  Rows r >= m re-read row 0
+    // (never used); steps below 0 re-read step 0 (the pointers stop there) and their work is skipped.
+    size_t rofs[MRR];
+    UNR for (int r = 0; r < MRR; r++) rofs[r] = (size_t)((MR > 0 && r < m) ? r : 0) * Bp;
+    auto fetch = [&](int slot, int kk) {  // loads of timestep max(kk, 0) into ring slot
+        xr[slot] = *Xp;
+        ur[slot] = *Up;
+        UNR for (int r = 0; r < MRR; r++) {
+            lr[slot][r] = ir[slot][r] = 0;
+            if (MR > 0) { lr[slot][r] = Lp[rofs[r]]; ir[slot][r] = Ip[rofs[r]]; }
         }
+        if (kk > 0) { Xp -= Vstep; Up -= Vstep; Lp -= Lstep; Ip -= Lstep; }  // uniform; no load inside the branch
     };
-    UNR for (int q = 0; q < PF; q++) fetch(q, T - 2 - q);
+    UNR for (int q = 0; q < PF; q++) { fetch(q, T - 2 - q); __builtin_amdgcn_sched_barrier(0); }  // keep issue order (vmcnt)
 
     for (int k0 = T - 2; k0 >= 0; k0 -= PF) {
       UNR for (int jj = 0; jj < PF; jj++) {
         const int k = k0 - jj;
-        if (k < 0) break;  // uniform
         const double xv = xr[jj], uv = ur[jj];
         double lam[MRR], Isk[MRR];
         UNR for (int r = 0; r < MRR; r++) { lam[r] = lr[jj][r]; Isk[r] = ir[jj][r]; }
         fetch(jj, k - PF);
+        if (k < 0) continue;  // uniform: dummy step of the last group
         // ---- vectors in: x, Qu = R u + dt p
         const double Qu = Rv * uv + dt * p;
         if (isV) { sV[g][0][v] = xv; sV[g][1][v] = Qu; }
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a) {
             Kji[e] -= Kstep;
         }
         if (ok && isV) *Dv_out = dv;
-        Dv_out -= Vstep;
+        Dv_out -= Kstep;
         // ---- stage derivatives l_xx (entries), l_x (vector component)
         double lxx[EPL], lx = 0;
         UNR for (int e = 0; e < EPL; e++) lxx[e] = 0;
@@ -236,6 +240,9 @@ __global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a) {
             const double* src = a.kpd + (size_t)kpi * kpd_stride;
             UNR for (int e = 0; e < EPL; e++) lxx[e] = AT(src, N + ei[e] * N + ej[e], bb);
             lx = AT(src, v, bb);
+            // consume the loads inside the branch: otherwise their wait lands after the join and every step drains vmcnt to 0
+            UNR for (int e = 0; e < EPL; e++) asm volatile("" : "+v"(lxx[e]));
+            asm volatile("" : "+v"(lx));
             kpi--;
             kp_next = (kpi >= 0) ? d.kp_t[kpi] : -1;
         } else if (lim_on) {
@@ -273,7 +280,7 @@ template <int LPI>
 static void launch_coop(bool al, const Bufs& a, int B, hipStream_t st) {
     constexpr int IPW = 64 / LPI;
     const dim3 grid(grid_x8((B + IPW - 1) / IPW)), block(64);
-    if (!al) hipLaunchKernelGGL((k_backward_si_coop<0, LPI>), grid, block, 0, st, a);
+    if (!al || a.m == 0) hipLaunchKernelGGL((k_backward_si_coop<0, LPI>), grid, block, 0, st, a);
     else if (a.m <= 1) hipLaunchKernelGGL((k_backward_si_coop<1, LPI>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((k_backward_si_coop<4, LPI>), grid, block, 0, st, a);
 }

@@ -28,7 +28,8 @@ __global__ __launch_bounds__(64) void k_forward_rows(Bufs a, FwdArgs f) {
     constexpr int DXS = NA * NXP + 2;             // per-instance stride (doubles), +16 B to spread the 8 instances over banks
     constexpr int XUP = ((NX + NU) + 1) & ~1;
     constexpr int XUS = NA * XUP + 2;
-    constexpr int NLD = NX + 2 + ND;              // doubles fetched per lane per step: K row | d | xbar (q, dq) | ubar
+    constexpr int ROWP = kd_rowp(NX), RS = NU * ROWP;
+    constexpr int NLD = ROWP + ND + 1;            // doubles fetched per lane per step: gain row {K row, d, pad} | xbar (q, dq) | ubar
     constexpr int PF = 4;
     __shared__ __attribute__((aligned(16))) double sDX[8 * DXS];
     __shared__ __attribute__((aligned(16))) double sXU[APPLY ? 8 * 8 : 8 * XUS];  // COST: gathered (x, u) per alpha at keypoint steps; APPLY: du^2 per row
@@ -61,11 +62,10 @@ __global__ __launch_bounds__(64) void k_forward_rows(Bufs a, FwdArgs f) {
 
     const int cur = a.cur[bb];
     // running source pointers for this lane's row
-    const double* pK = a.K + (size_t)(r * NX) * Bp + bb;
-    const double* pD = a.D + (size_t)r * Bp + bb;
+    const double* pK = a.KD + (size_t)bb * RS + r * ROWP;  // this lane's gain row {K[r][0..NX-1], d[r]}: 16-byte aligned, contiguous
     const double* pX = a.X[cur] + (size_t)r * Bp + bb;
     const double* pU = a.U[cur] + (size_t)r * Bp + bb;
-    const size_t sK_ = (size_t)NK * Bp, sU_ = (size_t)NU * Bp, sX_ = (size_t)NX * Bp;
+    const size_t sK_ = (size_t)Bp * RS, sU_ = (size_t)NU * Bp, sX_ = (size_t)NX * Bp;
     double* oX = a.X[1 - cur] + (size_t)r * Bp + bb;
     double* oU = a.U[1 - cur] + (size_t)r * Bp + bb;
 
@@ -74,14 +74,19 @@ __global__ __launch_bounds__(64) void k_forward_rows(Bufs a, FwdArgs f) {
     // the compiler then waits with vmcnt(0), i.e. for the prefetches it has just issued.  Past the end of the horizon
     // the pointers simply stop advancing (the last timestep is fetched again and never used).
     auto fetch = [&](int slot, int k) {
-        UNR for (int jx = 0; jx < NX; jx++) ring[slot][jx] = pK[(size_t)jx * Bp];
-        ring[slot][NX] = *pD;
-        UNR for (int q = 0; q < ND; q++) ring[slot][NX + 1 + q] = pX[(size_t)(q * DOF) * Bp];
-        ring[slot][NX + 1 + ND] = *pU;
+        UNR for (int q = 0; q < ROWP / 2; q++) {  // 16-byte loads
+            const double2 v2 = reinterpret_cast<const double2*>(pK)[q];
+            ring[slot][2 * q] = v2.x;
+            ring[slot][2 * q + 1] = v2.y;
+        }
+        UNR for (int q = 0; q < ND; q++) ring[slot][ROWP + q] = pX[(size_t)(q * DOF) * Bp];
+        ring[slot][ROWP + ND] = *pU;
         const size_t adv = (k < T - 2) ? 1 : 0;  // uniform
-        pK += adv * sK_; pD += adv * sU_; pX += adv * sX_; pU += adv * sU_;
+        pK += adv * sK_; pX += adv * sX_; pU += adv * sU_;
     };
-    UNR for (int q = 0; q < PF; q++) fetch(q, q);
+    // sched_barrier: the scheduler must not reorder the preamble's loads -- if slot 0 is issued last, the waitcnt pass merges
+    // "distance 0" into the loop header and every NS-th step drains the whole queue (vmcnt(6) instead of vmcnt(6 PF))
+    UNR for (int q = 0; q < PF; q++) { fetch(q, q); __builtin_amdgcn_sched_barrier(0); }
 
     // state of this lane's coordinate(s) for every alpha
     double xq[NA], xd[NA], pc[NA];
@@ -115,9 +120,9 @@ __global__ __launch_bounds__(64) void k_forward_rows(Bufs a, FwdArgs f) {
             if (k >= nsteps) break;  // uniform
             double Kr[NX];
             UNR for (int jx = 0; jx < NX; jx++) Kr[jx] = ring[jj][jx];
-            const double dr = ring[jj][NX], ub = ring[jj][NX + 1 + ND];
+            const double dr = ring[jj][NX], ub = ring[jj][ROWP + ND];
             double xb[ND];
-            UNR for (int q = 0; q < ND; q++) xb[q] = ring[jj][NX + 1 + q];
+            UNR for (int q = 0; q < ND; q++) xb[q] = ring[jj][ROWP + q];
             fetch(jj, k + PF);
             // ---- all-gather of dx(alpha)
             if (act) {
@@ -271,8 +276,9 @@ __global__ __launch_bounds__(64) void k_forward_lin(Bufs a, FwdArgs f) {
     constexpr int NX = S::NX, NU = S::NU, ND = S::ND, NK = NU * NX;
     constexpr int NXP = (NX + 1) & ~1;
     constexpr int DXS = NXP + 2;                  // per-instance stride (doubles) of the dx row, +16 B bank spread
-    constexpr int NLD = NX + 2 + ND;
-    constexpr int PF = 4;                         // timesteps in flight; PF * NLD loads must stay below the 6-bit vmcnt (63)
+    constexpr int ROWP = kd_rowp(NX), RS = NU * ROWP;
+    constexpr int NLD = ROWP + ND + 1;
+    constexpr int PF = 4;                         // timesteps in flight; (PF+1) * 6 load instructions stay below the 6-bit vmcnt (63)
     __shared__ __attribute__((aligned(16))) double sDX[8 * DXS];
     __shared__ __attribute__((aligned(16))) double sXB[8][NXP + 2];
     __shared__ __attribute__((aligned(16))) double sUB[8][10];
@@ -302,26 +308,29 @@ __global__ __launch_bounds__(64) void k_forward_lin(Bufs a, FwdArgs f) {
     const double my_alpha0 = ldexp(1.0, -r0), my_alpha1 = ldexp(1.0, -(r0 + 8));
 
     const int cur = a.cur[bb];
-    const double* pK = a.K + (size_t)(r * NX) * Bp + bb;
-    const double* pD = a.D + (size_t)r * Bp + bb;
+    const double* pK = a.KD + (size_t)bb * RS + r * ROWP;  // this lane's gain row {K[r][0..NX-1], d[r]}: 16-byte aligned, contiguous
     const double* pX = a.X[cur] + (size_t)r * Bp + bb;
     const double* pU = a.U[cur] + (size_t)r * Bp + bb;
-    const size_t sK_ = (size_t)NK * Bp, sU_ = (size_t)NU * Bp, sX_ = (size_t)NX * Bp;
+    const size_t sK_ = (size_t)Bp * RS, sU_ = (size_t)NU * Bp, sX_ = (size_t)NX * Bp;
     double* oX = a.X[1 - cur] + (size_t)r * Bp + bb;
     double* oU = a.U[1 - cur] + (size_t)r * Bp + bb;
 
     constexpr int NS = PF + 1;  // ring slots: the slot consumed in step k-1 receives step k+PF-1 ... no register copies, distance PF
     double ring[NS][NLD];
     auto fetch = [&](int slot, int k) {  // unconditional (see k_forward_rows); pointers stop at the last timestep
-        UNR for (int jx = 0; jx < NX; jx++) ring[slot][jx] = pK[(size_t)jx * Bp];
-        ring[slot][NX] = *pD;
-        UNR for (int q = 0; q < ND; q++) ring[slot][NX + 1 + q] = pX[(size_t)(q * DOF) * Bp];
-        ring[slot][NX + 1 + ND] = *pU;
-        if (k < T - 2) { pK += sK_; pD += sU_; pX += sX_; pU += sU_; }  // uniform; no load inside the branch
+        UNR for (int q = 0; q < ROWP / 2; q++) {  // 16-byte loads
+            const double2 v2 = reinterpret_cast<const double2*>(pK)[q];
+            ring[slot][2 * q] = v2.x;
+            ring[slot][2 * q + 1] = v2.y;
+        }
+        UNR for (int q = 0; q < ND; q++) ring[slot][ROWP + q] = pX[(size_t)(q * DOF) * Bp];
+        ring[slot][ROWP + ND] = *pU;
+        if (k < T - 2) { pK += sK_; pX += sX_; pU += sU_; }  // uniform; no load inside the branch
     };
-    UNR for (int q = 0; q < PF; q++) fetch(q, q);
     double xT[ND];  // xbar_{T-1} of this lane's coordinates (terminal step)
     UNR for (int q = 0; q < ND; q++) xT[q] = AT(a.X[cur], (T - 1) * NX + q * DOF + r, bb);
+    __builtin_amdgcn_sched_barrier(0);
+    UNR for (int q = 0; q < PF; q++) { fetch(q, q); __builtin_amdgcn_sched_barrier(0); }  // in issue order (see k_forward_rows)
 
     double dxq = 0, dxd = 0, pc[NA];
     UNR for (int al = 0; al < NA; al++) pc[al] = 0;
@@ -353,15 +362,18 @@ __global__ __launch_bounds__(64) void k_forward_lin(Bufs a, FwdArgs f) {
     };
 
     const int nsteps = T - 1;
+    // No `break` inside the unrolled group: a CFG path that skips a fetch makes the waitcnt pass assume the shortest distance
+    // between a slot's loads and its use (vmcnt(8) instead of vmcnt(6 PF)).  The last group runs dummy steps whose fetches
+    // re-read the last timestep and whose work is skipped.
     for (int k0 = 0; k0 < nsteps; k0 += NS) {
         UNR for (int jj = 0; jj < NS; jj++) {
             const int k = k0 + jj;
-            if (k >= nsteps) break;  // uniform
             fetch((jj + PF) % NS, k + PF);  // into the slot freed by the previous step
+            if (k >= nsteps) continue;  // uniform; skips the work, never a fetch
             const double* Kr = ring[jj];
-            const double dr = ring[jj][NX], ub = ring[jj][NX + 1 + ND];
+            const double dr = ring[jj][NX], ub = ring[jj][ROWP + ND];
             double xb[ND];
-            UNR for (int q = 0; q < ND; q++) xb[q] = ring[jj][NX + 1 + q];
+            UNR for (int q = 0; q < ND; q++) xb[q] = ring[jj][ROWP + q];
             // ---- all-gather of dx
             if (act) {
                 myDX[r] = dxq;

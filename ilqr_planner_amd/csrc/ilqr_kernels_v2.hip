@@ -119,15 +119,16 @@ __global__ __launch_bounds__(256) void k_forward_tile(Bufs a, FwdArgs f) {
     // per-thread load slots: address of step 0 and byte stride per timestep, resolved once (K | d | xbar | ubar regions)
     const double* lptr[NLD];
     size_t lstep[NLD];
+    constexpr int ROWP = kd_rowp(NX), RS = NU * ROWP;
     UNR for (int j = 0; j < NLD; j++) {
         const int c = lc0 + 16 * j;
-        const double* base = a.K;
-        int row = c, per = NK;
-        if (c >= NK + NU + NX) { base = Uc; row = c - NK - NU - NX; per = NU; }
-        else if (c >= NK + NU) { base = Xc; row = c - NK - NU; per = NX; }
-        else if (c >= NK) { base = a.D; row = c - NK; per = NU; }
-        lptr[j] = base + (size_t)row * Bp + lb;
-        lstep[j] = (size_t)per * Bp;
+        if (c >= NK + NU + NX) { lptr[j] = Uc + (size_t)(c - NK - NU - NX) * Bp + lb; lstep[j] = (size_t)NU * Bp; }
+        else if (c >= NK + NU) { lptr[j] = Xc + (size_t)(c - NK - NU) * Bp + lb; lstep[j] = (size_t)NX * Bp; }
+        else {  // gain record of instance lb: K[i][jj] at i*ROWP+jj, d[i] at i*ROWP+NX
+            const int off = (c >= NK) ? (c - NK) * ROWP + NX : (c / NX) * ROWP + (c % NX);
+            lptr[j] = a.KD + (size_t)lb * RS + off;
+            lstep[j] = (size_t)Bp * RS;
+        }
     }
     auto load_step = [&](int k, double* r) {
         if (k < T - 1) {  // uniform
@@ -351,8 +352,8 @@ __global__ __launch_bounds__(64) void k_backward_si(Bufs a) {
     const int cur = a.cur[b];
     const double* X = a.X[cur];
     const double* U = a.U[cur];
-    double* Kp = a.K;
-    double* Dp = a.D;
+    double* KDp = a.KD;
+    constexpr int ROWP = kd_rowp(N), RS = N * ROWP;
     const double dt = d.dt, idt = 1.0 / dt, idt2 = idt * idt, reg = d.reg;
     double Dg[N], Rd[N];
     UNR for (int i = 0; i < N; i++) { Rd[i] = d.R_diag[i]; Dg[i] = Rd[i] + reg; }
@@ -477,8 +478,8 @@ __global__ __launch_bounds__(64) void k_backward_si(Bufs a) {
         // K = (M D - I)/dt ; store K, d
         UNR for (int i = 0; i < N; i++) {
             UNR for (int j = 0; j < N; j++)
-                AT(Kp, k * N * N + i * N + j, b) = (M[sym(i, j)] * Dg[j] - ((i == j) ? 1.0 : 0.0)) * idt;
-            AT(Dp, k * N + i, b) = dv[i];
+                KD_REC(KDp, Bp, RS, k, b)[i * ROWP + j] = (M[sym(i, j)] * Dg[j] - ((i == j) ? 1.0 : 0.0)) * idt;
+            KD_REC(KDp, Bp, RS, k, b)[i * ROWP + N] = dv[i];
         }
         // stage derivatives (keypoint / limits / AL rows)
         double lx[N];
