@@ -304,6 +304,9 @@ extern "C" int ilqr_problem_create(ilqr_ctx* c, const ilqr_problem_desc* d, int 
     rc |= dalloc(p, &b.status, Bp);
     rc |= dalloc(p, &b.pend, Bp);
     rc |= dalloc(p, &b.pred, Bp);
+    rc |= dalloc(p, &b.lsc, (size_t)16 * Bp);
+    rc |= dalloc(p, &b.dun, Bp);
+    rc |= dalloc(p, &b.kpdev, (size_t)(d->n_kp > 0 ? d->n_kp : 1) * (NX + NU) * Bp);
     rc |= dalloc(p, &b.kpd, (size_t)(d->n_kp > 0 ? d->n_kp : 1) * (NX + NX * NX) * Bp);
     if (rc) { ilqr_problem_destroy(p); return 1; }
     b.U0 = U0; b.q0 = q0; b.dq0 = dq0; b.kp_tg = tg; b.desc = p->ddesc;
@@ -463,10 +466,12 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
     const char* fwd_env = std::getenv("ILQR_FWD");
     const bool fwd_rows = fwd_tile && forward_rows_supported(kind, nd, n_alpha) && !(fwd_env && !std::strcmp(fwd_env, "tile"));
     const bool fwd_lin = fwd_rows && !(fwd_env && !std::strcmp(fwd_env, "rows"));  // linear line search (PosOrn systems)
+    const bool fwd_wave = fwd_lin && forward_wave_supported(kind, nd, n_alpha);  // 32 lanes per instance + k_select
     const bool bwd_si = (path == 2) && backward_si_supported(kind, nd, al, p->bufs.m, p->bufs.per_step, p->con_state_only);
     FwdArgs f;
     std::memset(&f, 0, sizeof(f));
     f.line_search = line_search; f.early_stop = early_stop; f.nb_iter = nb_iter; f.penalty_roll = penalty; f.n_alpha = n_alpha; f.al = al ? 1 : 0; f.n_kp = p->desc.n_kp;
+    f.dbg = std::getenv("ILQR_DBG") ? std::atoi(std::getenv("ILQR_DBG")) : 0;
     {
         ProfScope ps(c, ILQR_PROF_ROLLOUT);
         launch_solver(kind, nd, KER_INIT, al, p->bufs, p->B, c->stream, f);
@@ -490,7 +495,8 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
         if (fwd_tile) {
             {
                 ProfScope ps(c, ILQR_PROF_FORWARD);
-                if (fwd_lin) launch_forward_lin(nd, KER_FWD_SPEC, p->bufs, p->B, p->T, c->stream, f);
+                if (fwd_wave) launch_forward_wave(p->bufs, p->B, c->stream, f);
+                else if (fwd_lin) launch_forward_lin(nd, KER_FWD_SPEC, p->bufs, p->B, p->T, c->stream, f);
                 else if (fwd_rows) launch_forward_rows(nd, KER_FWD_SPEC, p->bufs, p->B, c->stream, f);
                 else launch_solver_v2(kind, nd, KER_FWD_SPEC, al, p->bufs, p->B, p->T, c->stream, f);
             }

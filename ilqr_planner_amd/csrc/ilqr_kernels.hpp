@@ -27,6 +27,9 @@ struct Bufs {
     double* kpd;    // [n_kp][NX + NX*NX][Bp] l_x | l_xx of the keypoint steps of the current trajectory (k_kp_derivs)
     int* pend;      // [Bp] line-search winner index + 1 still to be applied by the APPLY pass (0 = nothing pending)
     int* pred;      // [Bp] predicted winner index of the next line search (= winner of the previous iteration)
+    double* lsc;    // [16][Bp] limit cost of the alpha = 1 rollout blended to every step size (k_forward_w32 -> k_select)
+    double* dun;    // [Bp] sum_k ||du_k(1)|| of that rollout
+    double* kpdev;  // [n_kp][NX+NU][Bp] deviation (dx, du) of that rollout at the keypoint steps
     double* cost_trace;   // [nb_iter][Bp] or null
     double* alpha_trace;  // [nb_iter][Bp] or null
     // augmented Lagrangian (shared constraint rows, per-instance multipliers)
@@ -46,6 +49,7 @@ struct FwdArgs {
     int al;       // 1 = AL_ILQR semantics (early stop without the cost test)
     int n_alpha;  // number of step sizes 1, 1/2, ... the line search may try (11 for alpha_floor = 1e-3)
     double penalty_roll, penalty_update;
+    int dbg;      // experiment switches (ILQR_DBG), 0 in production
 };
 
 // v1 (one lane per instance, generic): KER_INIT, KER_BACKWARD, KER_FORWARD
@@ -63,6 +67,8 @@ void launch_backward_si_coop(bool al, const Bufs& a, int B, hipStream_t st);
 bool forward_rows_supported(int kind, int nd, int n_alpha);
 void launch_forward_rows(int nd, int which, const Bufs& a, int B, hipStream_t st, const FwdArgs& f);
 void launch_forward_lin(int nd, int which, const Bufs& a, int B, int T, hipStream_t st, const FwdArgs& f);
+bool forward_wave_supported(int kind, int nd, int n_alpha);
+void launch_forward_wave(const Bufs& a, int B, hipStream_t st, const FwdArgs& f);
 void launch_fx_all(int kind, int nd, const Bufs& a, int B, int T, double* out, hipStream_t st);
 void launch_to_soa(const double* src, double* dst, int B, int Bp, int rows, hipStream_t st);
 void launch_from_soa(const double* src, double* dst, int B, int Bp, int rows, hipStream_t st);

@@ -117,13 +117,13 @@ __global__ __launch_bounds__(64) void k_forward_rows(Bufs a, FwdArgs f) {
     for (int k0 = 0; k0 < nsteps; k0 += PF) {
         UNR for (int jj = 0; jj < PF; jj++) {
             const int k = k0 + jj;
-            if (k >= nsteps) break;  // uniform
             double Kr[NX];
             UNR for (int jx = 0; jx < NX; jx++) Kr[jx] = ring[jj][jx];
             const double dr = ring[jj][NX], ub = ring[jj][ROWP + ND];
             double xb[ND];
             UNR for (int q = 0; q < ND; q++) xb[q] = ring[jj][ROWP + q];
             fetch(jj, k + PF);
+            if (k >= nsteps) continue;  // uniform; dummy step of the last group: the fetch is issued, the work skipped (see k_forward_lin)
             // ---- all-gather of dx(alpha)
             if (act) {
                 UNR for (int al = 0; al < NA; al++) {
@@ -337,7 +337,19 @@ __global__ __launch_bounds__(64) void k_forward_lin(Bufs a, FwdArgs f) {
     double kpc0 = 0, kpc1 = 0, dun = 0;
     double* myDX = sDX + g * DXS;
 
-    auto viol = [&](double v, int q) -> bool { return lw[q] != 0 && (v > smax[q] || v < smin[q]); };
+    // the segment [xbar, x(1)] of a coordinate leaves its limits iff the larger end exceeds the max or the smaller end is below
+    // the min; branch-free on purpose (short-circuit evaluation costs an exec-mask branch per term and step)
+    double emx[ND], emn[ND];
+    UNR for (int q = 0; q < ND; q++) { emx[q] = lw[q] ? smax[q] : INFINITY; emn[q] = lw[q] ? smin[q] : -INFINITY; }
+    auto seg_bad = [&](const double* xb_) -> bool {
+        const double e0 = xb_[0] + dxq;
+        bool bad = (fmax(xb_[0], e0) > emx[0]) | (fmin(xb_[0], e0) < emn[0]);
+        if (ND == 2) {
+            const double e1 = xb_[1] + dxd;
+            bad |= (fmax(xb_[1], e1) > emx[1]) | (fmin(xb_[1], e1) < emn[1]);
+        }
+        return bad;
+    };
     auto limit_cost_of = [&](double v, int q) -> double {
         double qv = 0, L = 0;
         if (lw[q] != 0) {
@@ -402,9 +414,7 @@ __global__ __launch_bounds__(64) void k_forward_lin(Bufs a, FwdArgs f) {
             }
             // ---- stage cost: limits (end-of-segment test first), task cost at keypoint steps
             if (lim_on) {
-                bool bad = viol(xb[0], 0) || viol(xb[0] + dxq, 0);
-                if (ND == 2) bad = bad || viol(xb[1], 1) || viol(xb[1] + dxd, 1);
-                if (__ballot((bad && act) ? 1 : 0) != 0ull) limits_all(xb);
+                if (__ballot((seg_bad(xb) & act) ? 1 : 0) != 0ull) limits_all(xb);
             }
             if (k == kp_next) {  // uniform, rare
                 if (act) {
@@ -437,9 +447,7 @@ __global__ __launch_bounds__(64) void k_forward_lin(Bufs a, FwdArgs f) {
         if (ND == 2) oX[(size_t)DOF * Bp] = xT[1] + dxd;
     }
     if (lim_on) {
-        bool bad = viol(xT[0], 0) || viol(xT[0] + dxq, 0);
-        if (ND == 2) bad = bad || viol(xT[1], 1) || viol(xT[1] + dxd, 1);
-        if (__ballot((bad && act) ? 1 : 0) != 0ull) limits_all(xT);
+        if (__ballot((seg_bad(xT) & act) ? 1 : 0) != 0ull) limits_all(xT);
     }
     if (kp_next == T - 1) {
         if (act) {

@@ -1,0 +1,325 @@
+// ilqr_kernels_wave.hip -- forward pass of the linear line search with 32 lanes per instance (PosOrn, nb_deriv = 1)
+//
+// k_forward_lin (ilqr_kernels_rows.hip) gives each instance 8 lanes: B = 4096 is then 512 single-wave workgroups, half of the
+// 1024 SIMDs stay empty and the other half run one wave whose per-step chain (LDS gather -> dot product -> sqrt -> dynamics)
+// is fully exposed.  Here the 7 x 8 gain record {K | d} of a step is spread over 32 lanes -- lane (r, jl) owns the two
+// adjacent entries (r, 2jl), (r, 2jl+1) and reads them with ONE 16-byte load, so a wave reads two whole records as 1 KiB
+// of contiguous memory -- and B = 4096 becomes 2048 waves, two per SIMD.  Per step and lane:
+//     partial = K[r][c0] dx[c0] + K[r][c1] dx[c1]          (c1 = 7 is the feed-forward column: dx[7] := 1)
+//     du[r]   = sum over the row's 4 lanes                 (two DPP quad permutes, no LDS)
+//     du[c0], du[c1] <- ds_bpermute from the rows c0, c1   (the transpose the product needs; LDS crossbar, no LDS memory)
+//     dx[c]  += dt du[c]                                    every lane keeps its two columns of the state deviation
+// The keypoint cost (FK) is not evaluated here: at keypoint steps the deviation (dx, du) is written to `kpdev`, and
+// k_select evaluates the task cost of all step sizes with one lane per (instance, alpha), picks the winner
+// (ILQRRecursive.cpp:101-155) and does the bookkeeping.  That keeps the FK call -- 256 VGPRs + scratch -- out of this kernel.
+#include <cstdlib>
+#include <cstring>
+
+#include "ilqr_step.hpp"
+
+namespace ilqr {
+
+#define LDS_ORDER() asm volatile("" ::: "memory")
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);  // old = src: every lane is written, no zero-fill moves
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// sum over the 4 lanes of a quad, result in all 4 (quad_perm [1,0,3,2] then [2,3,0,1])
+__device__ __forceinline__ double quad_sum(double v) {
+    v += dpp_f64<0xB1>(v);
+    v += dpp_f64<0x4E>(v);
+    return v;
+}
+__device__ __forceinline__ double bperm_f64(int byte_addr, double v) {
+    const int lo = __builtin_amdgcn_ds_bpermute(byte_addr, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(byte_addr, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+// Workgroup barrier that only drains LDS traffic (__syncthreads() also emits s_waitcnt vmcnt(0): it would wait for the gain
+// prefetches issued 7 steps ahead).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// One workgroup = 8 waves = 16 consecutive instances; a wave owns two of them (32 lanes each, see the file header).
+//   gains        : read by the owning wave straight from HBM, one 16-byte load per lane and step (a wave's two records are
+//                  1 KiB of contiguous memory), prefetched 7 steps ahead in a register ring
+//   xbar, ubar   : [row][b] layout -- 16 instances of one row are exactly one 128-byte line.  The workgroup loads a block of
+//                  S = 8 timesteps (112 lines) cooperatively, one block ahead, and stages it in LDS; the waves read their
+//                  values from there.  A wave loading its own two instances would touch 16 bytes of each line.
+//   x(1), u(1)   : written to an LDS block by the owning waves, stored by the whole workgroup as full lines once per block.
+//                  (Measured with 16-byte pieces stored by each wave: 0.09 ms of a 0.24 ms launch went into the stores.)
+// Two workgroup barriers per block of 8 steps; nothing else couples the waves.
+template <int NA>
+__global__ __launch_bounds__(512) void k_forward_wg(Bufs a, FwdArgs f) {
+    constexpr int NX = 7, NU = 7, ROWP = kd_rowp(NX), RS = NU * ROWP, NR = NX + NU;
+    static_assert(ROWP == 8, "record row = 7 gains + feed-forward");
+    constexpr int S = 8, PF = S - 1;     // block length = ring length: slot (step mod 8) is static in the unrolled block
+    constexpr int IW = 16;               // instances per workgroup
+    constexpr int NSEG = S * NR;         // 112 row segments (lines) per block
+    constexpr int NRND = (NSEG * IW + 511) / 512;  // loader rounds: 4 (the last one half used)
+    __shared__ double sIn[2][NSEG][IW];
+    __shared__ double sOut[NSEG][IW];
+
+    const DevDesc& d = *a.desc;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, g = lane >> 5, r8 = (lane >> 2) & 7, jl = lane & 3;
+    const int b0 = xcd_tile() * IW;
+    const int Bp = d.Bp, T = d.T, B = d.B;
+    {   // workgroup-uniform exit: every wave looks at all 16 instances
+        const int bi = b0 + (lane & 15);
+        const bool any = (bi < B) && (a.active[bi < B ? bi : 0] != 0);
+        if (__ballot(any ? 1 : 0) == 0ull) return;
+    }
+    const int li = wv * 2 + g;           // instance slot in the workgroup
+    const int b = b0 + li;
+    const bool inst_ok = (b < B) && (a.active[b < B ? b : 0] != 0);
+    const int bb = (b < B) ? b : 0;
+    const int r = r8 < NU ? r8 : NU - 1;  // row 7 shadows row 6 (never stores, never read by a bpermute)
+    const int c0 = 2 * jl, c1 = 2 * jl + 1;
+    const bool c1ok = c1 < NX;            // jl == 3: c1 is the feed-forward column
+    const int c1c = c1ok ? c1 : NX - 1;
+    const bool colst = inst_ok && (r8 == 0);               // row 0 publishes x (its 4 lanes hold all 7 columns)
+    const bool rowst = inst_ok && (jl == 0) && (r8 < NU);  // the first lane of a row publishes u
+    const int src0 = (g * 32 + c0 * 4) * 4, src1 = (g * 32 + c1c * 4) * 4;  // byte addresses for ds_bpermute
+
+    const double dt = d.dt, dt1 = c1ok ? dt : 0.0;
+    const int lim_on = d.limits_set;
+    const double pen = d.penalty;
+    const int lw0 = d.lw[c0], lw1 = c1ok ? d.lw[c1c] : 0;
+    const double mx0 = lw0 ? d.smax[c0] : INFINITY, mn0 = lw0 ? d.smin[c0] : -INFINITY;
+    const double mx1 = lw1 ? d.smax[c1c] : INFINITY, mn1 = lw1 ? d.smin[c1c] : -INFINITY;
+    const int n_kp = d.n_kp;
+    int kpi = 0, kp_next = (n_kp > 0) ? d.kp_t[0] : -1;
+
+    // ---- cooperative loader / writer: round q of thread tid handles (segment, instance) = ((q*512 + tid) / 16, tid % 16)
+    const int l_inst = tid & 15;
+    const int l_b = (b0 + l_inst < B) ? b0 + l_inst : 0;
+    const bool l_ok = (b0 + l_inst < B) && (a.active[l_b] != 0);
+    const int l_cur = a.cur[l_b];
+    const double* l_src[NRND];   // row base in the accepted trajectory (timestep 0)
+    double* l_dst[NRND];         // row base in the other buffer
+    int l_s[NRND], l_kmax[NRND];
+    size_t l_stride[NRND];
+    bool l_valid[NRND];
+    UNR for (int q = 0; q < NRND; q++) {
+        const int seg = (q * 512 + tid) >> 4;
+        l_valid[q] = seg < NSEG;
+        const int sg = l_valid[q] ? seg : 0;
+        const int s = sg / NR, row = sg % NR;
+        l_s[q] = s;
+        if (row < NX) {
+            l_src[q] = a.X[l_cur] + (size_t)row * Bp + l_b;
+            l_dst[q] = a.X[1 - l_cur] + (size_t)row * Bp + l_b;
+            l_stride[q] = (size_t)NX * Bp;
+            l_kmax[q] = T - 1;
+        } else {
+            l_src[q] = a.U[l_cur] + (size_t)(row - NX) * Bp + l_b;
+            l_dst[q] = a.U[1 - l_cur] + (size_t)(row - NX) * Bp + l_b;
+            l_stride[q] = (size_t)NU * Bp;
+            l_kmax[q] = T - 2;
+        }
+    }
+    double pre[NRND];
+    auto block_load = [&](int k0) {  // unconditional; timesteps beyond the end re-read the last one
+        UNR for (int q = 0; q < NRND; q++) {
+            const int k = k0 + l_s[q];
+            pre[q] = l_src[q][(size_t)(k < l_kmax[q] ? k : l_kmax[q]) * l_stride[q]];
+        }
+    };
+    auto block_stage = [&](int buf) {
+        UNR for (int q = 0; q < NRND; q++)
+            if (l_valid[q]) (&sIn[buf][0][0])[q * 512 + tid] = pre[q];
+    };
+    auto block_store = [&](int k0) {
+        UNR for (int q = 0; q < NRND; q++) {
+            const int k = k0 + l_s[q];
+            if (l_valid[q] && l_ok && k <= l_kmax[q]) l_dst[q][(size_t)k * l_stride[q]] = (&sOut[0][0])[q * 512 + tid];
+        }
+    };
+
+    // ---- gain ring
+    const double* pK = a.KD + (size_t)bb * RS + r * ROWP + c0;  // 16-byte aligned
+    const size_t sK_ = (size_t)Bp * RS;
+    double rk0[S], rk1[S];
+    auto fetch = [&](int slot, int k) {  // unconditional; the pointer stops at the last timestep
+        const double2 v2 = *reinterpret_cast<const double2*>(pK);
+        rk0[slot] = v2.x;
+        rk1[slot] = v2.y;
+        if (k < T - 2) pK += sK_;  // uniform; no load inside the branch
+    };
+    block_load(0);
+    __builtin_amdgcn_sched_barrier(0);
+    UNR for (int q = 0; q < PF; q++) { fetch(q, q); __builtin_amdgcn_sched_barrier(0); }  // issue order matters (vmcnt)
+    block_stage(0);
+    block_load(S);
+    lds_barrier();
+
+    double dx0 = 0, dx1 = c1ok ? 0.0 : 1.0, dun = 0, pcA = 0, pcB = 0;
+
+    // a coordinate's segment [xbar, x(1)] leaves [mn, mx] iff its larger end exceeds mx or its smaller end is below mn
+    // (+-inf stand for weight 0); branch-free on purpose
+    auto seg_bad = [&](double xa, double xb) -> bool {
+        const double ea = xa + dx0, eb = xb + dx1;
+        return (fmax(xa, ea) > mx0) | (fmin(xa, ea) < mn0) | (fmax(xb, eb) > mx1) | (fmin(xb, eb) < mn1);
+    };
+    // inspectJointLimit on one coordinate (System.cpp:163-179): q = limit - v on the violated side, cost q * penalty * q.
+    // Branch-free: the distance beyond the limit is max(v - mx, 0) + max(mn - v, 0), and (-q) pen (-q) == q pen q bit for bit.
+    auto limit_cost_of = [&](double v, double mx, double mn) -> double {
+        const double q = fmax(v - mx, 0.0) + fmax(mn - v, 0.0);
+        return q * pen * q;
+    };
+    // Limit cost of the stage for every alpha: all 8 rows of an instance hold the full state deviation, so row r8 evaluates
+    // alpha_{r8} = 2^-r8 and alpha_{r8+8} for its two columns -- two evaluations instead of a loop over n_alpha in row 0.
+    const double myA = ldexp(1.0, -r8), myB = ldexp(1.0, -(r8 + 8));
+    auto limits_all = [&](double xb0, double xb1) {
+        pcA += limit_cost_of(fma(myA, dx0, xb0), mx0, mn0) + limit_cost_of(fma(myA, dx1, xb1), mx1, mn1);
+        if (NA > 8) pcB += limit_cost_of(fma(myB, dx0, xb0), mx0, mn0) + limit_cost_of(fma(myB, dx1, xb1), mx1, mn1);
+    };
+    double* kpdev = a.kpdev;
+
+    // steps 0 .. T-2 are control steps, step T-1 is the terminal state, later steps of the last block are dummies
+    const int nblocks = (T + S - 1) / S;
+    for (int j = 0; j < nblocks; j++) {
+        const int k0 = j * S, buf = j & 1;
+        UNR for (int s = 0; s < S; s++) {
+            const int k = k0 + s;
+            fetch((s + PF) % S, k + PF);  // into the slot freed by the previous step
+            if (k > T - 1) continue;      // uniform; dummy step (the fetch is issued, the work skipped)
+            const double xb0 = sIn[buf][s * NR + c0][li], xb1 = sIn[buf][s * NR + c1c][li];
+            if (k < T - 1) {
+                const double ub = sIn[buf][s * NR + NX + r][li];
+                const double du = quad_sum(fma(rk0[s], dx0, rk1[s] * dx1));
+                const double du0 = bperm_f64(src0, du), du1 = bperm_f64(src1, du);
+                if (colst) {
+                    sOut[s * NR + c0][li] = xb0 + dx0;
+                    if (c1ok) sOut[s * NR + c1][li] = xb1 + dx1;
+                }
+                if (rowst) sOut[s * NR + NX + r][li] = ub + du;
+                if (f.early_stop) {  // ||du_k(1)||
+                    const double n2 = quad_sum(fma(du0, du0, c1ok ? du1 * du1 : 0.0));
+                    dun += __builtin_amdgcn_sqrt(n2);  // v_sqrt_f64: the sum only feeds the stop threshold
+                }
+                if (lim_on && __ballot((seg_bad(xb0, xb1) & inst_ok) ? 1 : 0) != 0ull) limits_all(xb0, xb1);
+                if (k == kp_next) {  // uniform, rare: hand the deviation of this step to k_select
+                    double* o = kpdev + (size_t)kpi * NR * Bp;
+                    if (colst) {
+                        AT(o, c0, bb) = dx0;
+                        if (c1ok) AT(o, c1, bb) = dx1;
+                    }
+                    if (rowst) AT(o, NX + r, bb) = du;
+                    kpi++;
+                    kp_next = (kpi < n_kp) ? d.kp_t[kpi] : -1;
+                }
+                // ---- deviation dynamics: dx' = dx + dt du
+                dx0 = dx0 + dt * du0;
+                dx1 = dx1 + dt1 * du1;
+            } else {  // terminal state
+                if (colst) {
+                    sOut[s * NR + c0][li] = xb0 + dx0;
+                    if (c1ok) sOut[s * NR + c1][li] = xb1 + dx1;
+                }
+                if (lim_on && __ballot((seg_bad(xb0, xb1) & inst_ok) ? 1 : 0) != 0ull) limits_all(xb0, xb1);
+                if (kp_next == T - 1 && colst) {
+                    double* o = kpdev + (size_t)kpi * NR * Bp;
+                    AT(o, c0, bb) = dx0;
+                    if (c1ok) AT(o, c1, bb) = dx1;
+                }
+            }
+        }
+        lds_barrier();            // block j computed by every wave: sOut complete, sIn[buf] free
+        block_store(k0);
+        block_stage(buf ^ 1);     // block j+1 (loaded while block j was computed)
+        block_load(k0 + 2 * S);
+        lds_barrier();            // sIn[buf^1] visible, sOut free
+    }
+    // ---- limit cost per alpha (sum over the 7 columns = the 4 lanes of a row; row r8 holds alpha_{r8}, alpha_{r8+8})
+    {
+        const double sA = quad_sum(pcA), sB = quad_sum(pcB);
+        if (inst_ok && jl == 0) {
+            if (r8 < NA) AT(a.lsc, r8, bb) = sA;
+            if (NA > 8 && r8 + 8 < NA) AT(a.lsc, r8 + 8, bb) = sB;
+        }
+    }
+    if (colst && jl == 0) a.dun[bb] = dun;
+}
+
+// Line-search decision of iteration f.it, one lane per (instance, alpha): task cost of x(alpha) = xbar + alpha dx at the keypoint
+// steps + the limit cost k_forward_w32 accumulated; the first alpha (descending) whose cost is below the current one wins, else
+// the last one tried (ILQRRecursive.cpp:101-155).  Writes cost/alpha/iters/status/traces, `pend` for k_blend/k_flip, and the
+// early-stop flag.
+template <class S, int NA>
+__global__ __launch_bounds__(64) void k_select(Bufs a, FwdArgs f) {
+    constexpr int NX = S::NX, NU = S::NU;
+    static_assert(NA <= 16, "16 lanes per instance");
+    const DevDesc& d = *a.desc;
+    const int lane = threadIdx.x, gi = lane >> 4, al = lane & 15;
+    const int b = blockIdx.x * 4 + gi;
+    const int Bp = d.Bp, T = d.T, B = d.B;
+    const bool inst_ok = (b < B) && (a.active[b < B ? b : 0] != 0);
+    const int bb = (b < B) ? b : 0;
+    const int n_alpha = f.n_alpha < NA ? f.n_alpha : NA;
+    const bool mine = inst_ok && al < n_alpha;
+    const double aa = ldexp(1.0, -al);
+    double c = 0;
+    if (mine) {
+        const double* Xb = a.X[a.cur[bb]];
+        const double* Ub = a.U[a.cur[bb]];
+        for (int kpi = 0; kpi < d.n_kp; kpi++) {
+            const int k = d.kp_t[kpi];
+            const double* dv = a.kpdev + (size_t)kpi * (NX + NU) * Bp;
+            double xt[NX], ut[NU], tg[S::NF];
+            UNR for (int i = 0; i < NX; i++) xt[i] = fma(aa, AT(dv, i, bb), AT(Xb, k * NX + i, bb));
+            UNR for (int i = 0; i < NU; i++) ut[i] = (k < T - 1) ? fma(aa, AT(dv, NX + i, bb), AT(Ub, k * NU + i, bb)) : 0.0;
+            UNR for (int i = 0; i < S::NF; i++) tg[i] = AT(a.kp_tg, kpi * S::NF + i, bb);
+            c += kp_cost<S>(d, kpi, tg, xt, ut);
+        }
+        c += AT(a.lsc, al, bb);
+    }
+    const double cost0 = a.cost[bb];
+    const bool okc = mine && !((c >= cost0) || isnan(c));
+    const unsigned m16 = (unsigned)((__ballot(okc ? 1 : 0) >> (gi * 16)) & 0xffffull);
+    const int w = m16 ? (__ffs(m16) - 1) : (n_alpha - 1);
+    const double wcost = __shfl(c, gi * 16 + w);
+    if (inst_ok && al == 0) {
+        const double walpha = ldexp(1.0, -w);
+        a.cost[bb] = wcost;
+        a.alpha[bb] = walpha;
+        a.iters[bb] = f.it + 1;
+        a.status[bb] = (isfinite(wcost) ? 0 : 1) | ((walpha <= d.alpha_floor) ? 2 : 0);
+        if (a.cost_trace) {
+            a.cost_trace[(size_t)f.it * Bp + bb] = wcost;
+            a.alpha_trace[(size_t)f.it * Bp + bb] = walpha;
+        }
+        a.pend[bb] = w + 1;  // k_blend / k_flip finish the acceptance (w == 0: the buffer already holds x(1), u(1))
+        a.pred[bb] = w;
+        bool stop = f.early_stop && (walpha * sqrt(walpha * a.dun[bb]) < d.stop_tol);  // sum ||du(alpha)|| = alpha sum ||du(1)||
+        if (!f.al) stop = stop && (wcost < 1e-3);  // ILQRRecursive.cpp:174 vs AL-ILQR.cpp:225
+        if (stop) a.active[bb] = 0;
+    }
+}
+
+bool forward_wave_supported(int kind, int nd, int n_alpha) {
+    static const bool off = std::getenv("ILQR_FWD") && !std::strcmp(std::getenv("ILQR_FWD"), "lin");
+    return !off && kind == 0 && nd == 1 && n_alpha <= 16;
+}
+
+void launch_forward_wave(const Bufs& a, int B, hipStream_t st, const FwdArgs& f) {
+    using S = Sys<0, 1>;
+    const dim3 grid(grid_x8((B + 15) / 16)), block(512);
+    const dim3 sgrid((B + 3) / 4), sblock(64);
+    if (f.n_alpha <= 1) {
+        hipLaunchKernelGGL((k_forward_wg<1>), grid, block, 0, st, a, f);
+        hipLaunchKernelGGL((k_select<S, 1>), sgrid, sblock, 0, st, a, f);
+    } else if (f.n_alpha <= 11) {
+        hipLaunchKernelGGL((k_forward_wg<11>), grid, block, 0, st, a, f);
+        hipLaunchKernelGGL((k_select<S, 11>), sgrid, sblock, 0, st, a, f);
+    } else {
+        hipLaunchKernelGGL((k_forward_wg<16>), grid, block, 0, st, a, f);
+        hipLaunchKernelGGL((k_select<S, 16>), sgrid, sblock, 0, st, a, f);
+    }
+}
+
+}  // namespace ilqr
