@@ -474,7 +474,15 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
     f.dbg = std::getenv("ILQR_DBG") ? std::atoi(std::getenv("ILQR_DBG")) : 0;
     {
         ProfScope ps(c, ILQR_PROF_ROLLOUT);
-        launch_solver(kind, nd, KER_INIT, al, p->bufs, p->B, c->stream, f);
+        if (path != 1 && init_lti_supported(kind, nd)) {
+            launch_init_lti(nd, p->bufs, p->B, c->stream);
+            if (al) {  // active-set weights of the initial trajectory: I_k = penalty * (g<0 && lambda==0 ? 0 : 1)
+                f.it = -1; f.do_update = 0;
+                launch_solver_v2(kind, nd, KER_AL_UPDATE, al, p->bufs, p->B, p->T, c->stream, f);
+            }
+        } else {
+            launch_solver(kind, nd, KER_INIT, al, p->bufs, p->B, c->stream, f);
+        }
     }
     HIPCHK(c, hipGetLastError());
     for (int it = 0; it < nb_iter; it++) {
