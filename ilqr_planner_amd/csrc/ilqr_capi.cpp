@@ -508,7 +508,10 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
                 else if (fwd_rows) launch_forward_rows(nd, KER_FWD_SPEC, p->bufs, p->B, c->stream, f);
                 else launch_solver_v2(kind, nd, KER_FWD_SPEC, al, p->bufs, p->B, p->T, c->stream, f);
             }
-            if (fwd_rows) {  // the cost pass writes no trajectory: the winner is always re-rolled
+            if (fwd_wave) {  // winner applied, AL bookkeeping and buffer flip in one pass over the trajectory
+                ProfScope ps(c, ILQR_PROF_APPLY);
+                launch_apply_wave(p->bufs, p->B, p->T, c->stream, f);
+            } else if (fwd_rows) {  // the cost pass writes no trajectory: the winner is always re-rolled
                 ProfScope ps(c, ILQR_PROF_APPLY);
                 if (fwd_lin) launch_forward_lin(nd, KER_FWD_APPLY, p->bufs, p->B, p->T, c->stream, f);
                 else launch_forward_rows(nd, KER_FWD_APPLY, p->bufs, p->B, c->stream, f);
@@ -516,7 +519,7 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
                 ProfScope ps(c, ILQR_PROF_APPLY);
                 launch_solver_v2(kind, nd, KER_FWD_APPLY, al, p->bufs, p->B, p->T, c->stream, f);
             }
-            if (al) {  // active-set weights of the accepted trajectory (+ multiplier update every `lag` iterations)
+            if (al && !fwd_wave) {  // active-set weights of the accepted trajectory (+ multiplier update every `lag` iterations)
                 ProfScope ps(c, ILQR_PROF_OTHER);
                 launch_solver_v2(kind, nd, KER_AL_UPDATE, al, p->bufs, p->B, p->T, c->stream, f);
             }

@@ -301,6 +301,68 @@ __global__ __launch_bounds__(64) void k_select(Bufs a, FwdArgs f) {
     }
 }
 
+// Accepted trajectory + AL bookkeeping in one pass (k_blend and k_al_post each re-read the trajectory): one thread per
+// (timestep, instance), a block = 16 timesteps x 16 instances (16 instances of a row = one 128-byte line).
+//   x(alpha) = xbar + alpha (x(1) - xbar) written over x(1) unless alpha = 1; on that accepted (x, u) the AL bookkeeping of
+//   AL-ILQR.cpp:190,202-208: I_k = penalty (g<0 && lambda==0 ? 0 : 1) with the multipliers BEFORE the update,
+//   lambda_k = max(0, lambda_k + penalty' g) on update iterations.  k_flip then swaps the buffers of the instances that ran.
+template <class S>
+__global__ __launch_bounds__(256) void k_apply(Bufs a, FwdArgs f) {
+    constexpr int NX = S::NX, NU = S::NU;
+    const DevDesc& d = *a.desc;
+    const int tid = threadIdx.x, inst = tid & 15, hi = tid >> 4;
+    const int b = blockIdx.x * 16 + inst, k = blockIdx.y * 16 + hi;
+    const int Bp = d.Bp, T = d.T;
+    if (b >= d.B || k >= T) return;
+    const int w = a.pend[b] - 1;  // winner index of this iteration (k_select), -1: the instance did not run
+    if (w < 0) return;
+    const int cur = a.cur[b];
+    const double aa = ldexp(1.0, -w);
+    const double* Xb = a.X[cur];
+    const double* Ub = a.U[cur];
+    double* Xn = a.X[1 - cur];
+    double* Un = a.U[1 - cur];
+    const int m = f.al ? a.m : 0;
+    if (w == 0 && (m == 0 || k == T - 1)) return;  // nothing to blend, no constraint rows at this step
+    double x[NX], u[NU];
+    UNR for (int i = 0; i < NX; i++) x[i] = AT(Xn, k * NX + i, b);
+    if (k < T - 1) { UNR for (int i = 0; i < NU; i++) u[i] = AT(Un, k * NU + i, b); }
+    if (w > 0) {
+        double xb[NX], ub[NU];
+        UNR for (int i = 0; i < NX; i++) xb[i] = AT(Xb, k * NX + i, b);
+        if (k < T - 1) { UNR for (int i = 0; i < NU; i++) ub[i] = AT(Ub, k * NU + i, b); }
+        UNR for (int i = 0; i < NX; i++) {
+            x[i] = fma(aa, x[i] - xb[i], xb[i]);
+            AT(Xn, k * NX + i, b) = x[i];
+        }
+        if (k < T - 1) {
+            UNR for (int i = 0; i < NU; i++) {
+                u[i] = fma(aa, u[i] - ub[i], ub[i]);
+                AT(Un, k * NU + i, b) = u[i];
+            }
+        }
+    }
+    if (k < T - 1) {
+        for (int r = 0; r < m; r++) {
+            const double g = con_g<S>(a, k, r, x, u);
+            const double lam = AT(a.lambda, k * m + r, b);
+            AT(a.Is, k * m + r, b) = f.penalty_roll * ((g < 0 && lam == 0) ? 0.0 : 1.0);
+            if (f.do_update) {
+                const double v = lam + f.penalty_update * g;
+                AT(a.lambda, k * m + r, b) = v > 0 ? v : 0;
+            }
+        }
+    }
+}
+__global__ void k_flip_ran(Bufs a) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.desc->B) return;
+    if (a.pend[b] > 0) {
+        a.cur[b] = 1 - a.cur[b];
+        a.pend[b] = 0;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ initial rollout (PosOrn)
 // k_init_rollout (ilqr_kernels.hip) walks the horizon with one lane per instance: 64 waves for B = 4096, 0.85 ms -- as much as
 // 1.3 iterations.  For PosOrn systems the coordinates integrate independently, so the rollout is one lane per (instance,
@@ -394,6 +456,12 @@ void launch_init_lti(int nd, const Bufs& a, int B, hipStream_t st) {
 bool forward_wave_supported(int kind, int nd, int n_alpha) {
     static const bool off = std::getenv("ILQR_FWD") && !std::strcmp(std::getenv("ILQR_FWD"), "lin");
     return !off && kind == 0 && nd == 1 && n_alpha <= 16;
+}
+
+void launch_apply_wave(const Bufs& a, int B, int T, hipStream_t st, const FwdArgs& f) {
+    using S = Sys<0, 1>;
+    hipLaunchKernelGGL((k_apply<S>), dim3((B + 15) / 16, (T + 15) / 16), dim3(256), 0, st, a, f);
+    hipLaunchKernelGGL(k_flip_ran, dim3((B + 255) / 256), dim3(256), 0, st, a);
 }
 
 void launch_forward_wave(const Bufs& a, int B, hipStream_t st, const FwdArgs& f) {
