@@ -159,19 +159,23 @@ __global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a) {
         // ---- vectors in: x, Qu = R u + dt p
         const double Qu = Rv * uv + dt * p;
         if (isV) { sV[g][0][v] = xv; sV[g][1][v] = Qu; }
-        // ---- S = D + dt^2 P, full storage
+        // ---- S = D + dt^2 P.  The kernel is bound by LDS bandwidth (128 B/clk per CU: a 64-lane b64 access is 4 clk whatever
+        // the lanes do), so during the sweeps only the lower triangle is kept (ONE write per entry and sweep; the reads pick
+        // sA[i][c] or sA[c][i]) and the last sweep's result goes out once, negated, into the full matrix for the row products.
         double s[EPL];
         UNR for (int e = 0; e < EPL; e++) {
             s[e] = dt2 * P[e] + (dg[e] ? Di[e] : 0.0);
             *sAij[e] = s[e];
-            *sAji[e] = s[e];
         }
         LDS_ORDER();
         // ---- symmetric sweeps: after the 7 pivots the matrix holds -S^-1
         double r = rcp_nr(sA[g][0][0]);
         UNR for (int c = 0; c < N; c++) {
             double aic[EPL], ajc[EPL];
-            UNR for (int e = 0; e < EPL; e++) { aic[e] = rowI[e][c]; ajc[e] = rowJ[e][c]; }
+            UNR for (int e = 0; e < EPL; e++) {
+                aic[e] = *((c <= ei[e]) ? &sA[g][ei[e]][c] : &sA[g][c][ei[e]]);
+                ajc[e] = *((c <= ej[e]) ? &sA[g][ej[e]][c] : &sA[g][c][ej[e]]);
+            }
             double rn = 0;
             if (c + 1 < N) {  // next pivot after this sweep: a_{c+1,c+1} - a_{c+1,c}^2 / a_cc
                 const double an = sA[g][c + 1][c + 1], anc = sA[g][c + 1][c];
@@ -185,8 +189,7 @@ __global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a) {
                 if (ei[e] == c) val = ajc[e] * r;      // entry (c, j), j != c : a_cj / d
                 if (ei[e] == c && ej[e] == c) val = -r;
                 s[e] = val;
-                *sAij[e] = val;
-                *sAji[e] = val;
+                if (c + 1 < N) *sAij[e] = val;
             }
             LDS_ORDER();
             r = rn;
@@ -206,11 +209,13 @@ __global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a) {
             UNR for (int q = 1; q < N; q += 2) s1 += rowI[e][q] * rowJ[e][q];
             m2[e] = s0 + s1;
         }
+        double rv[N];  // row v of M, read once for dv and M d
+        UNR for (int q = 0; q < N; q++) rv[q] = rowV[q];
         double dv;
         {
             double s0 = 0, s1 = 0;
-            UNR for (int q = 0; q < N; q += 2) s0 += rowV[q] * sV[g][1][q];
-            UNR for (int q = 1; q < N; q += 2) s1 += rowV[q] * sV[g][1][q];
+            UNR for (int q = 0; q < N; q += 2) s0 += rv[q] * sV[g][1][q];
+            UNR for (int q = 1; q < N; q += 2) s1 += rv[q] * sV[g][1][q];
             dv = -(s0 + s1);
         }
         if (isV) sV[g][2][v] = dv;
@@ -218,8 +223,8 @@ __global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a) {
         double Md;
         {
             double s0 = 0, s1 = 0;
-            UNR for (int q = 0; q < N; q += 2) s0 += rowV[q] * sV[g][2][q];
-            UNR for (int q = 1; q < N; q += 2) s1 += rowV[q] * sV[g][2][q];
+            UNR for (int q = 0; q < N; q += 2) s0 += rv[q] * sV[g][2][q];
+            UNR for (int q = 1; q < N; q += 2) s1 += rv[q] * sV[g][2][q];
             Md = s0 + s1;
         }
         // ---- gains out
