@@ -29,6 +29,21 @@ __device__ __forceinline__ double rcp_nr(double x) {  // 1/x: v_rcp_f64 + two Ne
 }
 #define LDS_ORDER() asm volatile("" ::: "memory")
 
+// DPP move of a double (two 32-bit halves); quad_perm / row_half_mirror build an 8-lane butterfly without LDS traffic.
+template <int CTRL>
+__device__ __forceinline__ double dpp64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double oct_sum(double v) {  // sum over lanes 8m .. 8m+7, result in all eight
+    v += dpp64<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp64<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp64<0x141>(v);  // row_half_mirror
+    return v;
+}
+
 template <int MR, int LPI>
 __global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a) {
     constexpr int N = 7, IPW = 64 / LPI, EPL = (28 + LPI - 1) / LPI;
@@ -211,7 +226,9 @@ __global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a) {
         }
         double rv[N];  // row v of M, read once for dv and M d
         UNR for (int q = 0; q < N; q++) rv[q] = rowV[q];
-        double dv;
+        // (Qu_q and dv_q could come from lane q by DPP row_newbcast instead of LDS: measured 3 % slower -- the two broadcasts sit
+        // on the dv -> M d dependency chain.)
+        double dv, Md;
         {
             double s0 = 0, s1 = 0;
             UNR for (int q = 0; q < N; q += 2) s0 += rv[q] * sV[g][1][q];
@@ -220,7 +237,6 @@ __global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a) {
         }
         if (isV) sV[g][2][v] = dv;
         LDS_ORDER();
-        double Md;
         {
             double s0 = 0, s1 = 0;
             UNR for (int q = 0; q < N; q += 2) s0 += rv[q] * sV[g][2][q];
@@ -264,7 +280,11 @@ __global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a) {
             UNR for (int rr = 0; rr < MRR; rr++) {
                 if (rr < m) {
                     double gr = -bbr[rr];
-                    UNR for (int q = 0; q < N; q++) gr += Arow[rr][q] * sV[g][0][q];
+                    if (LPI >= 16) {  // A_r . x: every vector lane multiplies its own component, 8-lane butterfly (lane 7 adds 0)
+                        gr += oct_sum(isV ? Av[rr] * xv : 0.0);
+                    } else {
+                        UNR for (int q = 0; q < N; q++) gr += Arow[rr][q] * sV[g][0][q];
+                    }
                     UNR for (int e = 0; e < EPL; e++) lxx[e] += Ai[rr][e] * Isk[rr] * Aj[rr][e];
                     lx += Av[rr] * (lam[rr] + Isk[rr] * gr);
                 }
