@@ -99,8 +99,10 @@ def test_tutorial_traces_on_gpu(ctx, name, idx):
     p.close()
 
 
-@pytest.mark.parametrize("cfg_name,B,nb_iter", [("C2", 256, 20), ("C3r", 128, 12), ("C3", 96, 12), ("C2nd", 64, 10), ("C4t1", 64, 12), ("C4", 48, 6)])
-def test_random_batch_vs_oracle(ctx, cfg_name, B, nb_iter):
+@pytest.mark.parametrize("cfg_name,B,nb_iter,limits", [("C2", 256, 20, "inactive"), ("C3r", 128, 12, "inactive"), ("C3", 96, 12, "inactive"),
+                                                       ("C2nd", 64, 10, "inactive"), ("C4t1", 64, 12, "inactive"), ("C4", 48, 6, "inactive"),
+                                                       ("C2", 64, 12, "urdf"), ("C3", 64, 12, "urdf"), ("C2nd", 32, 8, "urdf")])
+def test_random_batch_vs_oracle(ctx, cfg_name, B, nb_iter, limits):
     """Seeded random batches: final cost within 1e-4 relative of the oracle.
 
     iLQR with the reference's accept-anyway line search (and, for AL, the active-set mask `g<0 && lambda==0`) is a
@@ -110,7 +112,7 @@ def test_random_batch_vs_oracle(ctx, cfg_name, B, nb_iter):
     from ilqr_planner_amd import workloads
 
     cfg = workloads.config(cfg_name)
-    desc, inp = workloads.make_batch(ctx, cfg, B=B)
+    desc, inp = workloads.make_batch(ctx, cfg, B=B, limits=limits)  # "urdf": the joint limits of the Panda, active penalties
     p = workloads.load_batch(ctx, desc, inp, B)
     workloads.run_solver(p, cfg, nb_iter=nb_iter, early_stop=True)
     cost, iters, X, U = p.cost(), p.iters(), p.X(), p.U()
