@@ -49,6 +49,11 @@ static int is_zero(const double* a, int n) {
 }
 
 /* Eigen MatrixXd::inverse() on a dynamic-size matrix = PartialPivLU, then solve against identity. */
+/* Test aid, not part of the restated algorithm: bit 0 replaces Qxu = A'PB by Qux' in the backward sweep.  The two are equal in
+   exact arithmetic; tests use the switch to show that an instance's result depends on rounding-level reassociation. */
+static int g_variant = 0;
+void orc_set_variant(int v) { g_variant = v; }
+
 int orc_inverse(int n, const double* A, double* Ainv) {
     double* lu = (double*)malloc(sizeof(double) * n * n);
     int* piv = (int*)malloc(sizeof(int) * n);
@@ -526,6 +531,8 @@ static int solve_riccati(const orc_system* s, const orc_constraints* c, double* 
             mm(tmp, AtP, A, nx, nx, nx);
             for (int i = 0; i < nx * nx; i++) Qxx[i] = lxx[i] + tmp[i];
             mm(Qxu, AtP, B, nx, nx, nu);                 /* cost_xu = 0 */
+            if (g_variant & 1) /* test aid: Qxu := Qux^T, identical in exact arithmetic (P symmetric) */
+                for (int i = 0; i < nx; i++) for (int j = 0; j < nu; j++) Qxu[i * nu + j] = Qux[j * nx + i];
             mtm(Qu, B, p, nx, nu, 1);
             for (int i = 0; i < nu; i++) Qu[i] = s->R_diag[i] * uk[i] + Qu[i]; /* cost_u = R u for ALL k */
             orc_cost_x(s, xk, k, lx);

@@ -126,6 +126,7 @@ void orc_psi_linear(int dim, int K, double* out);
 
 /* general inverse by LU with partial pivoting (Eigen MatrixXd::inverse() = PartialPivLU). returns 0 ok */
 int orc_inverse(int n, const double* A, double* Ainv);
+void orc_set_variant(int v);  /* test aid: bit 0 = Qxu := Qux^T in the backward sweep (equal in exact arithmetic) */
 
 #ifdef __cplusplus
 }

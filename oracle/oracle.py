@@ -115,6 +115,8 @@ def lib():
             getattr(L, "orc_psi_" + n).argtypes = [C.c_int, C.c_int, dp]
         L.orc_inverse.argtypes = [C.c_int, dp, dp]
         L.orc_inverse.restype = C.c_int
+        L.orc_set_variant.argtypes = [C.c_int]
+        L.orc_set_variant.restype = None
         for n in ("orc_sd_logmap", "orc_sd_expmap"):
             getattr(L, n).argtypes = [dp, dp, dp]
         L.orc_sd_transport.argtypes = [dp, dp, dp, dp]
@@ -368,3 +370,8 @@ def inverse(A):
     o = np.zeros((n, n))
     lib().orc_inverse(n, _dp(A), _dp(o))
     return o
+
+
+def set_variant(v: int):
+    """Test aid: bit 0 makes the backward sweep use Qxu := Qux^T (equal to A'PB in exact arithmetic)."""
+    lib().orc_set_variant(int(v))

@@ -6,17 +6,18 @@ from ilqr_planner_amd import capi, workloads
 from tests.helpers import oracle_solve_instance, panda_segs
 
 name, B, nb_iter = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+limits = sys.argv[4] if len(sys.argv) > 4 else "inactive"
 ctx = capi.Context(0)
 cfg = workloads.config(name)
-desc, inp = workloads.make_batch(ctx, cfg, B=B)
+desc, inp = workloads.make_batch(ctx, cfg, B=B, limits=limits)
 p = workloads.load_batch(ctx, desc, inp, B)
-workloads.run_solver(p, cfg, nb_iter=nb_iter, early_stop=False)
+workloads.run_solver(p, cfg, nb_iter=nb_iter, early_stop=True)
 cost, iters = p.cost(), p.iters()
 ct, at = p.trace(nb_iter)
 segs = panda_segs()
 nd = 0
 for i in range(B):
-    r = oracle_solve_instance(cfg, inp, i, nb_iter, False, segs)
+    r = oracle_solve_instance(cfg, inp, i, nb_iter, True, segs)
     rel = abs(cost[i] - r["cost"]) / max(abs(r["cost"]), 1e-12)
     same = np.array_equal(at[i, : r["iters"]], r["trace_alpha"])
     if not same or rel > 1e-6:

@@ -61,7 +61,7 @@ def sig6(x):
     return float("%.6g" % x)
 
 
-def assert_trace(got_cost, got_alpha, trace):
+def assert_trace(got_cost, got_alpha, trace, ulps=0.51):
     assert len(got_cost) == len(trace), (len(got_cost), len(trace))
     for i, ((c_ref, a_ref), c, a) in enumerate(zip(trace, got_cost, got_alpha)):
         assert sig6(a) == a_ref, f"iteration {i+1}: alpha {a} != {a_ref}"
@@ -70,7 +70,7 @@ def assert_trace(got_cost, got_alpha, trace):
         else:
             # the printed value has 6 significant digits: allow half a unit in the last place (+ slack for rounding ties)
             ulp6 = 10.0 ** (np.floor(np.log10(abs(c_ref))) - 5)
-            assert abs(c - c_ref) <= 0.51 * ulp6, f"iteration {i+1}: cost {c!r} vs {c_ref!r}"
+            assert abs(c - c_ref) <= ulps * ulp6, f"iteration {i+1}: cost {c!r} vs {c_ref!r}"
 
 
 # ----------------------------------------------------------------------------- synthetic batches (ilqr_planner_amd.workloads) -> oracle
