@@ -27,6 +27,28 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def pmc_traffic(category):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary (profiles/*_kernels.txt, two
+    separate passes: FETCH_SIZE, WRITE_SIZE; on gfx950 FETCH_SIZE counts half of a coalesced stream, so it is doubled --
+    MI355X_MICROARCH.md).  bench.py cannot run the profiler around itself; the summary is produced by
+    scripts/collect_profiles.sh with this same command.  Returns (bytes or None, source)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_kernels.txt")))
+    if not files:
+        return None, None
+    fetch = write = None
+    for line in open(files[-1]):
+        if ("k_" + category) not in line:
+            continue
+        if "FETCH_SIZE" in line:
+            fetch = float(line.split("avg=")[1].split()[0]) * 1024 * 2
+        elif "WRITE_SIZE" in line:
+            write = float(line.split("avg=")[1].split()[0]) * 1024
+    if fetch is None or write is None:
+        return None, None
+    return int(fetch + write), "profiles/" + os.path.basename(files[-1])
+
+
 def algorithmic_bytes(nx, nu, m, T, B):
     """fp64 bytes one launch of each kernel must move if A_k, B_k are never stored (SURVEY.md 8d model):
     backward: read x,u ; write K,d (+ read lambda, I_k for AL)
@@ -167,8 +189,9 @@ def main():
         roof = None
         if dom:
             k = kern[dom]
+            traffic, traffic_src = pmc_traffic(dom) if args.config == "C3" and not v1 else (None, None)
             roof = dict(bound="hbm", kernel=dom, achieved=round(k["gbs"], 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(k["gbs"] / HBM_PEAK_GBS, 5),
-                        traffic=None, avg_launch_ms=round(k["avg_ms"], 4), alg_bytes_per_launch=int(k["alg_bytes"]),
+                        traffic=traffic, traffic_source=traffic_src, avg_launch_ms=round(k["avg_ms"], 4), alg_bytes_per_launch=int(k["alg_bytes"]),
                         other={n: dict(avg_launch_ms=round(v["avg_ms"], 4), achieved=round(v["gbs"], 2)) for n, v in kern.items() if n != dom},
                         mean_line_search_trials=round(trials, 3))
         out = {

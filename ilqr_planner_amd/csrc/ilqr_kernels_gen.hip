@@ -205,7 +205,7 @@ __global__ __launch_bounds__(64) void k_backward_gen(Bufs a) {
             double v;
             if (TM && i == NU - 1) {
                 double s0 = 0;
-                UNR for (int q = 0; q < NX; q++) s0 += sbc[q] * sP[q][j];
+                _Pragma("unroll 3") for (int q = 0; q < NX; q++) s0 += sbc[q] * sP[q][j];
                 v = s0;
             } else {
                 v = (ND == 1) ? dt * sP[i][j] : hdt2 * sP[i][j] + dt * sP[DOF + i][j];
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(64) void k_backward_gen(Bufs a) {
         {
             if (TM && uj == NU - 1) {
                 double s0 = 0;
-                UNR for (int q = 0; q < NX; q++) s0 += sBtP[ui][q] * sbc[q];
+                _Pragma("unroll 3") for (int q = 0; q < NX; q++) s0 += sBtP[ui][q] * sbc[q];
                 Quu_e = s0;
             } else {
                 Quu_e = (ND == 1) ? sBtP[ui][uj] * dt : sBtP[ui][uj] * hdt2 + sBtP[ui][DOF + uj] * dt;
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(64) void k_backward_gen(Bufs a) {
             auto atp = [&](int cc) { return is_vrow(i) ? dt * sP[i - DOF][cc] + sP[i][cc] : sP[i][cc]; };
             if (TM && j == NU - 1) {
                 double s0 = 0;
-                UNR for (int q = 0; q < NX; q++) s0 += atp(q) * sbc[q];
+                _Pragma("unroll 3") for (int q = 0; q < NX; q++) s0 += atp(q) * sbc[q];
                 Qxu_e[t] = s0;
             } else {
                 Qxu_e[t] = (ND == 1) ? atp(j) * dt : atp(j) * hdt2 + atp(DOF + j) * dt;
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(64) void k_backward_gen(Bufs a) {
         double Qu_v = 0, Qx_v = 0;
         if (TM && l == NU - 1) {
             double s0 = 0;
-            UNR for (int q = 0; q < NX; q++) s0 += sbc[q] * sp[q];
+            _Pragma("unroll 3") for (int q = 0; q < NX; q++) s0 += sbc[q] * sp[q];
             Qu_v = Ru * uv + s0;
         } else {
             const double pv = (ND == 1) ? dt * sp[vu] : hdt2 * sp[vu] + dt * sp[DOF + vu];
@@ -341,24 +341,27 @@ __global__ __launch_bounds__(64) void k_backward_gen(Bufs a) {
         LDS_ORDER();
         // ---- 7. P' = Qxx + K^T T1 + Qux^T K ; p' = Qx + K^T tq + Qux^T d
         {
-            double kr[BLK][NU], qr[BLK][NU], tc[BLK][NU], kc[BLK][NU];
-            UNR for (int r = 0; r < BLK; r++) {
-                const int i = (bi * BLK + r) < NX ? bi * BLK + r : 0, j = (bj * BLK + r) < NX ? bj * BLK + r : 0;
-                UNR for (int q = 0; q < NU; q++) { kr[r][q] = sKt[i][q]; qr[r][q] = sQxu[i][q]; tc[r][q] = sT1t[j][q]; kc[r][q] = sKt[j][q]; }
+            // rank-1 accumulation over the control index: 4 BLK operands live at a time (a fully unrolled version keeps 64 doubles
+            // in flight and pushes the kernel to 256 VGPRs = one wave per SIMD)
+            int ri[BLK], cj[BLK];
+            UNR for (int r = 0; r < BLK; r++) { ri[r] = (bi * BLK + r) < NX ? bi * BLK + r : 0; cj[r] = (bj * BLK + r) < NX ? bj * BLK + r : 0; }
+            double acc0[BLK * BLK], acc1[BLK * BLK];
+            UNR for (int q = 0; q < BLK * BLK; q++) acc0[q] = acc1[q] = 0;
+            double ps0 = 0, ps1 = 0;
+            _Pragma("unroll 2") for (int q = 0; q < NU; q++) {
+                double kr[BLK], qr[BLK], tc[BLK], kc[BLK];
+                UNR for (int r = 0; r < BLK; r++) { kr[r] = sKt[ri[r]][q]; qr[r] = sQxu[ri[r]][q]; tc[r] = sT1t[cj[r]][q]; kc[r] = sKt[cj[r]][q]; }
+                UNR for (int r = 0; r < BLK; r++)
+                    UNR for (int c = 0; c < BLK; c++) { acc0[r * BLK + c] += kr[r] * tc[c]; acc1[r * BLK + c] += qr[r] * kc[c]; }
+                ps0 += sKt[vx][q] * stq[q];
+                ps1 += sQxu[vx][q] * sd[q];
             }
-            double pv = 0;
-            {
-                double s0 = 0, s1 = 0;
-                UNR for (int q = 0; q < NU; q++) { s0 += sKt[vx][q] * stq[q]; s1 += sQxu[vx][q] * sd[q]; }
-                pv = (Qx_v + s0) + s1;
-            }
+            const double pv = (Qx_v + ps0) + ps1;
             LDS_ORDER();
             UNR for (int r = 0; r < BLK; r++)
                 UNR for (int c = 0; c < BLK; c++) {
-                    double s0 = 0, s1 = 0;
-                    UNR for (int q = 0; q < NU; q++) { s0 += kr[r][q] * tc[c][q]; s1 += qr[r][q] * kc[c][q]; }
                     const int i = bi * BLK + r, j = bj * BLK + c;
-                    if (blv && i < NX && j < NX) sP[i][j] = (Qxx_b[r * BLK + c] + s0) + s1;
+                    if (blv && i < NX && j < NX) sP[i][j] = (Qxx_b[r * BLK + c] + acc0[r * BLK + c]) + acc1[r * BLK + c];
                 }
             if (isX) sp[vx] = pv;
         }
