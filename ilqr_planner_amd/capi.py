@@ -56,6 +56,9 @@ class ProblemDesc(C.Structure):
         ("n_kp", C.c_int),
         ("kp_timestep", C.c_int * MAX_KP),
         ("kp_Q", (C.c_double * (MAX_NQ * MAX_NQ)) * MAX_KP),
+        ("kp_dist", C.c_int * MAX_KP),
+        ("kp_pos_radius", C.c_double * MAX_KP),
+        ("kp_orn_thresh", (C.c_double * 3) * MAX_KP),
         ("reg", C.c_double),
         ("alpha_floor", C.c_double),
         ("stop_tol", C.c_double),
@@ -146,7 +149,7 @@ def chain_from_urdf(urdf_text: str, base: str, tip: str, tool_rpy=None, tool_xyz
                 lower=lo[: d.dof].copy(), upper=up[: d.dof].copy())
 
 
-def make_desc(*, kind, nb_deriv, horizon, dt, R_diag, chain, kp_timesteps, kp_Q, limits=None) -> ProblemDesc:
+def make_desc(*, kind, nb_deriv, horizon, dt, R_diag, chain, kp_timesteps, kp_Q, limits=None, kp_dist=None) -> ProblemDesc:
     """chain: dict(seg_joint, seg_xyz, seg_R, seg_axis, dof); limits: dict(state_max, state_min, limit_weight, penalty) or None."""
     L = load()
     d = ProblemDesc()
@@ -182,6 +185,12 @@ def make_desc(*, kind, nb_deriv, horizon, dt, R_diag, chain, kp_timesteps, kp_Q,
         for a in range(nq):
             for b in range(nq):
                 d.kp_Q[k][a * nq + b] = Q[a, b]
+    for k, kd in enumerate(kp_dist or []):  # PosOrnKeypointDistFunct: None or dict(pos_radius=..., orn_thresh=[3])
+        if kd is not None:
+            d.kp_dist[k] = 1
+            d.kp_pos_radius[k] = float(kd["pos_radius"])
+            for i in range(3):
+                d.kp_orn_thresh[k][i] = float(kd["orn_thresh"][i])
     return d
 
 

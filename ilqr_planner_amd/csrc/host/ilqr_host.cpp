@@ -310,6 +310,32 @@ Vec PosOrnKeypoint::diff(const Vec& state) const {  // PosOrnKeypoint.cpp:24-45
     return res;
 }
 
+static void check_thresh(const Vec& t) {
+    if (t.size() != 3) throw std::runtime_error("[PosOrnKeypointDistFunct] orn_thresh must have 3 entries");
+}
+PosOrnKeypointDistFunct::PosOrnKeypointDistFunct(const Vec& position, const Vec& orientation, const Mat& precision, const double& pos_radius,
+                                                 const Vec& orn_thresh, const int& timestep)
+    : PosOrnKeypoint(position, orientation, precision, timestep), pos_radius_(pos_radius), orn_thresh_(orn_thresh) { check_thresh(orn_thresh); }
+PosOrnKeypointDistFunct::PosOrnKeypointDistFunct(const Vec& position, const Vec& dposition, const Vec& orientation, const Vec& dorientation,
+                                                 const Mat& precision, const double& pos_radius, const Vec& orn_thresh, const int& timestep)
+    : PosOrnKeypoint(position, dposition, orientation, dorientation, precision, timestep), pos_radius_(pos_radius), orn_thresh_(orn_thresh) { check_thresh(orn_thresh); }
+Vec PosOrnKeypointDistFunct::diff(const Vec& state) const {  // PosOrnKeypointDistFunct.cpp:13-35
+    Vec r = PosOrnKeypoint::diff(state);
+    const double n = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    if (n <= pos_radius_) {
+        r[0] = r[1] = r[2] = 0;
+    } else {
+        const double f = n - pos_radius_;
+        for (int i = 0; i < 3; i++) r[i] = r[i] / n * f;
+    }
+    for (int i = 0; i < 3; i++) {
+        const double v = r[3 + i];
+        if (std::fabs(v) <= orn_thresh_[i]) r[3 + i] = 0;
+        else r[3 + i] = v - (v < 0 ? -1 : 1) * orn_thresh_[i];
+    }
+    return r;
+}
+
 SpacetimeKeypoint::SpacetimeKeypoint(const Vec& position, const Vec& orientation, const Mat& precision, const double& continuous_time, const int& timestep)
     : PosOrnKeypoint(position, orientation, precision, timestep), continuous_time_(continuous_time) { TAG_ = "POS_ORN_TIME"; }
 SpacetimeKeypoint::SpacetimeKeypoint(const Vec& position, const Vec& dposition, const Vec& orientation, const Vec& dorientation, const Mat& precision,
@@ -454,6 +480,11 @@ void System::lower(ilqr_problem_desc* d) const {
         if (P.rows != nb_Q_var_ || P.cols != nb_Q_var_) throw std::runtime_error("[System] keypoint precision must be nb_Q_var x nb_Q_var");
         for (int a = 0; a < nb_Q_var_; a++)
             for (int b = 0; b < nb_Q_var_; b++) d->kp_Q[k][a * nb_Q_var_ + b] = P(a, b);
+        if (auto* df = dynamic_cast<const PosOrnKeypointDistFunct*>(keypoints[k].get())) {  // dead zones (PosOrnKeypointDistFunct.cpp:13-35)
+            d->kp_dist[k] = 1;
+            d->kp_pos_radius[k] = df->getPosRadius();
+            for (int i = 0; i < 3; i++) d->kp_orn_thresh[k][i] = df->getOrnThresh()[i];
+        }
     }
 }
 

@@ -147,6 +147,20 @@ protected:
     int state_size_;
 };
 
+class PosOrnKeypointDistFunct : public PosOrnKeypoint {  // PosOrnKeypointDistFunct.h:15-44
+public:
+    PosOrnKeypointDistFunct(const Vec& position, const Vec& orientation, const Mat& precision, const double& pos_radius, const Vec& orn_thresh, const int& timestep);
+    PosOrnKeypointDistFunct(const Vec& position, const Vec& dposition, const Vec& orientation, const Vec& dorientation, const Mat& precision,
+                            const double& pos_radius, const Vec& orn_thresh, const int& timestep);
+    Vec diff(const Vec& state) const override;  // PosOrnKeypointDistFunct.cpp:13-35
+    double getPosRadius() const { return pos_radius_; }
+    Vec getOrnThresh() const { return orn_thresh_; }
+
+protected:
+    double pos_radius_;
+    Vec orn_thresh_;
+};
+
 class SpacetimeKeypoint : public PosOrnKeypoint {  // SpacetimeKeypoint.h:15-45
 public:
     SpacetimeKeypoint(const Vec& position, const Vec& orientation, const Mat& precision, const double& continuous_time, const int& timestep);

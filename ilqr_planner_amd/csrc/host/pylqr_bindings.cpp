@@ -141,6 +141,12 @@ PYBIND11_MODULE(PyLQR, m) {
              py::arg("dorientation"), py::arg("precision"), py::arg("timestep"))
         .def("get_position", &sys::PosOrnKeypoint::getPosition)
         .def("get_orientation", &sys::PosOrnKeypoint::getOrientation);
+    // bindings.cpp:302-306 (argument names pos_thresh / orn_thresh as there)
+    py::class_<sys::PosOrnKeypointDistFunct, sys::PosOrnKeypoint, std::shared_ptr<sys::PosOrnKeypointDistFunct>>(m_sys, "PosOrnKeypointDistFunct")
+        .def(py::init<const Vec&, const Vec&, const Mat&, const double&, const Vec&, const int&>(), py::arg("position"), py::arg("orientation"), py::arg("precision"),
+             py::arg("pos_thresh"), py::arg("orn_thresh"), py::arg("timestep"))
+        .def(py::init<const Vec&, const Vec&, const Vec&, const Vec&, const Mat&, const double&, const Vec&, const int&>(), py::arg("position"), py::arg("dposition"),
+             py::arg("orientation"), py::arg("dorientation"), py::arg("precision"), py::arg("pos_thresh"), py::arg("orn_thresh"), py::arg("timestep"));
     py::class_<sys::SpacetimeKeypoint, sys::PosOrnKeypoint, std::shared_ptr<sys::SpacetimeKeypoint>>(m_sys, "SpacetimeKeypoint")
         .def(py::init<const Vec&, const Vec&, const Mat&, const double&, const int&>(), py::arg("position"), py::arg("orientation"), py::arg("precision"),
              py::arg("continuous_time"), py::arg("timestep"))

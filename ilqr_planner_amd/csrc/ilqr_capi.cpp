@@ -244,6 +244,9 @@ static int lower_desc(ilqr_ctx* c, const ilqr_problem_desc& d, int B, int Bp, De
         if (k > 0 && d.kp_timestep[k] <= d.kp_timestep[k - 1]) return fail(c, "keypoint timesteps must be unique and ascending");
         h.kp_t[k] = d.kp_timestep[k];
         for (int i = 0; i < dm.n_Q * dm.n_Q; i++) h.kp_Q[k][i] = d.kp_Q[k][i];
+        h.kp_dist[k] = d.kp_dist[k];
+        h.kp_pos_radius[k] = d.kp_pos_radius[k];
+        for (int i = 0; i < 3; i++) h.kp_orn_thresh[k][i] = d.kp_orn_thresh[k][i];
     }
     h.reg = d.reg; h.alpha_floor = d.alpha_floor; h.stop_tol = d.stop_tol;
     return 0;

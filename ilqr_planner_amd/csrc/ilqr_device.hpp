@@ -43,6 +43,8 @@ struct DevDesc {
     int kp_t[MAX_KP];
     double reg, alpha_floor, stop_tol;
     double kp_Q[MAX_KP][MAX_NQ * MAX_NQ];  // leading dimension n_Q
+    int kp_dist[MAX_KP];               // PosOrnKeypointDistFunct dead zones (0 = plain keypoint)
+    double kp_pos_radius[MAX_KP], kp_orn_thresh[MAX_KP][3];
 };
 
 template <int KIND_, int ND_>
@@ -251,6 +253,29 @@ ILQR_DEV void kp_diff(const double* tg, const double* fxv, double* e) {
     if (S::TM) e[S::NQ - 1] = tg[S::NF - 1] - fxv[S::NF - 1];
 }
 
+// PosOrnKeypointDistFunct::diff (PosOrnKeypointDistFunct.cpp:13-35) applied to the residual of PosOrnKeypoint::diff: the
+// position part is shrunk by the radius along its direction (zero inside the ball), every orientation component by its
+// threshold towards zero.  The Jacobian used by cost_x / cost_xx is the plain one (the reference does not differentiate the
+// dead zone either).
+ILQR_DEV void kp_deadzone(const DevDesc& d, int kpi, double* e) {
+    if (!d.kp_dist[kpi]) return;
+    const double rad = d.kp_pos_radius[kpi];
+    const double n = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+    if (n <= rad) {
+        e[0] = e[1] = e[2] = 0;
+    } else {
+        const double f = n - rad;
+#pragma unroll
+        for (int i = 0; i < 3; i++) e[i] = e[i] / n * f;  // normalized() * (norm - radius)
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const double th = d.kp_orn_thresh[kpi][i], v = e[3 + i];
+        if (fabs(v) <= th) e[3 + i] = 0;
+        else e[3 + i] = v - (v < 0 ? -1.0 : 1.0) * th;
+    }
+}
+
 // limits (inspectJointLimit, System.cpp:121-142): returns sum q_i L_ii q_i ; optionally adds -L q to lx and L^2 to diag(lxx)
 template <class S>
 ILQR_DEV double limit_cost(const DevDesc& d, const double* x) {
@@ -275,6 +300,7 @@ ILQR_DEV double kp_cost(const DevDesc& d, int kpi, const double* tg, const doubl
     double fxv[S::NF], e[S::NQ];
     fx_of<S, false>(d, x, fxv, nullptr);
     kp_diff<S>(tg, fxv, e);
+    kp_deadzone(d, kpi, e);
     const double* Q = d.kp_Q[kpi];
     double c = 0;
 #pragma unroll

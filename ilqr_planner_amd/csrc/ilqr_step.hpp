@@ -50,6 +50,7 @@ ILQR_DEV void stage_derivs(const DevDesc& d, const Bufs& a, int b, const double*
         fx_of<S, true>(d, x, fxv, J);
         UNR for (int i = 0; i < NF; i++) tg[i] = AT(a.kp_tg, kpi * NF + i, b);
         kp_diff<S>(tg, fxv, e);
+        kp_deadzone(d, kpi, e);
         const double* Q = d.kp_Q[kpi];
         UNR for (int i = 0; i < NQ; i++) {
             double s = 0;

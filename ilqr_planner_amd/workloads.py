@@ -34,6 +34,11 @@ def config(name: str):
         "C3": dict(kind=capi.SYS_POS_ORN, nb_deriv=1, T=200, dt=0.05, B=4096, seed=2, Qdiag=[P, P], solver="al", nb_iter=20,
                    al=dict(row=5, bound=2.0, penalty=0.25, scaling=1.1, lag=5)),
         "C3r": dict(kind=capi.SYS_POS_ORN, nb_deriv=1, T=200, dt=0.05, B=4096, seed=2, Qdiag=[P, P], solver="recursive", nb_iter=20),
+        # PosOrnKeypointDistFunct: dead zones of 5 cm / 0.1 rad at the via point, 1 cm / mixed thresholds at the goal
+        "C3d": dict(kind=capi.SYS_POS_ORN, nb_deriv=1, T=100, dt=0.05, B=256, seed=8, Qdiag=[P, P], solver="recursive", nb_iter=15,
+                    kp_dist=[dict(pos_radius=0.05, orn_thresh=[0.1, 0.1, 0.1]), dict(pos_radius=0.01, orn_thresh=[0.02, 0.2, 0.0])]),
+        "C2ndd": dict(kind=capi.SYS_POS_ORN, nb_deriv=2, T=100, dt=0.05, B=256, seed=9, Qdiag=[P + [1, 1, 1, 0, 0, 0], P + V], solver="recursive",
+                      nb_iter=10, kp_dist=[dict(pos_radius=0.03, orn_thresh=[0.05, 0.05, 0.05]), None]),
         "C4": dict(kind=capi.SYS_POS_ORN_TIME, nb_deriv=2, T=200, dt=None, B=4096, seed=3, Qdiag=[P + V + [.1], P + V + [.1]],
                    ctimes=[2.5, 5.0], solver="recursive", nb_iter=20),
         "C5": dict(kind=capi.SYS_POS_ORN, nb_deriv=1, T=400, dt=0.01, B=8192, seed=4, Qdiag=[P, P], solver="batch_cp", nb_iter=10,
@@ -72,7 +77,8 @@ def make_batch(ctx: capi.Context, cfg: dict, B: int | None = None, seed: int | N
     if nd == 2:
         smax[dof:2 * dof], smin[dof:2 * dof], w[dof:2 * dof] = 10.0, -10.0, 1
     desc = capi.make_desc(kind=kind, nb_deriv=nd, horizon=T, dt=cfg["dt"], R_diag=[1e-5] * nu, chain=chain, kp_timesteps=kp_t,
-                          kp_Q=[np.diag(q) for q in cfg["Qdiag"]], limits=dict(state_max=smax, state_min=smin, limit_weight=w, penalty=1.0))
+                          kp_Q=[np.diag(q) for q in cfg["Qdiag"]], limits=dict(state_max=smax, state_min=smin, limit_weight=w, penalty=1.0),
+                          kp_dist=cfg.get("kp_dist"))
     q0 = np.clip(Q0_TUT[None, :] + rng.uniform(-0.3, 0.3, (B, dof)), lo, up)
     targets = []
     for i in range(2):

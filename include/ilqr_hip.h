@@ -80,6 +80,12 @@ typedef struct {
     int n_kp;
     int kp_timestep[ILQR_MAX_KP];
     double kp_Q[ILQR_MAX_KP][ILQR_MAX_NQ * ILQR_MAX_NQ]; /* row-major n_Q x n_Q, leading dimension n_Q */
+    /* PosOrnKeypointDistFunct (src/system/PosOrnKeypointDistFunct.cpp:13-35): dead zones on the residual of keypoint k --
+     * position part shrunk by kp_pos_radius towards 0 (0 inside the ball), each orientation component by kp_orn_thresh.
+     * kp_dist[k] = 0: plain PosOrnKeypoint (the default; NOT the same as radius 0, which renormalises the residual). */
+    int kp_dist[ILQR_MAX_KP];
+    double kp_pos_radius[ILQR_MAX_KP];
+    double kp_orn_thresh[ILQR_MAX_KP][3];
     double reg;          /* 1e-6 */
     double alpha_floor;  /* 1e-3 */
     double stop_tol;     /* 1e-3 */

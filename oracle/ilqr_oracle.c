@@ -306,6 +306,20 @@ void orc_kp_diff(const orc_system* s, const orc_keypoint* kp, const double* fx, 
         }
     }
     if (tm) e[s->n_Q - 1] = kp->ctime - fx[s->n_f - 1];
+    if (kp->dist) { /* PosOrnKeypointDistFunct::diff, PosOrnKeypointDistFunct.cpp:13-35 (no trace exercises it: pinned by reading only) */
+        double n = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+        if (n <= kp->pos_radius) { /* :18-19 */
+            e[0] = e[1] = e[2] = 0;
+        } else { /* :21 normalized() * (norm - radius) */
+            double f = n - kp->pos_radius;
+            for (int i = 0; i < 3; i++) e[i] = e[i] / n * f;
+        }
+        for (int i = 0; i < 3; i++) { /* :25-32; `abs` taken as the floating-point overload */
+            double v = e[3 + i];
+            if (fabs(v) <= kp->orn_thresh[i]) e[3 + i] = 0;
+            else e[3 + i] = v - (v < 0 ? -1 : 1) * kp->orn_thresh[i];
+        }
+    }
 }
 
 static const orc_keypoint* find_kp(const orc_system* s, int k) { /* System.cpp:96-101; later duplicates win in the map */

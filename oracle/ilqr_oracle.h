@@ -52,6 +52,8 @@ typedef struct {
     double dpos[3], dorn[4];    /* 2nd order only */
     double ctime;               /* time systems only */
     double Q[ORC_MAX_NQ * ORC_MAX_NQ]; /* row-major n_Q x n_Q precision */
+    int dist;                   /* 1 = PosOrnKeypointDistFunct (PosOrnKeypointDistFunct.h:15-44) */
+    double pos_radius, orn_thresh[3];
 } orc_keypoint;
 
 typedef struct {

@@ -44,6 +44,9 @@ class Keypoint(C.Structure):
         ("dorn", C.c_double * 4),
         ("ctime", C.c_double),
         ("Q", C.c_double * (MAX_NQ * MAX_NQ)),
+        ("dist", C.c_int),
+        ("pos_radius", C.c_double),
+        ("orn_thresh", C.c_double * 3),
     ]
 
 
@@ -270,6 +273,11 @@ def make_system(segs, kind, nb_deriv, T, dt, R_diag, keypoints, q0, dq0=None, qM
         for a in range(nq):
             for b in range(nq):
                 kp.Q[a * nq + b] = Q[a, b]
+        if k.get("dist") is not None:  # PosOrnKeypointDistFunct: dict(pos_radius, orn_thresh[3])
+            kp.dist = 1
+            kp.pos_radius = float(k["dist"]["pos_radius"])
+            for j in range(3):
+                kp.orn_thresh[j] = float(k["dist"]["orn_thresh"][j])
     return s
 
 

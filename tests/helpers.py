@@ -89,6 +89,8 @@ def oracle_system_of_instance(cfg, inp, i, segs=None):
             d.update(dpos=tg[7:10], dorn=tg[10:14])
         if tm:
             d["ctime"] = tg[-1]
+        if cfg.get("kp_dist") and cfg["kp_dist"][k] is not None:
+            d["dist"] = cfg["kp_dist"][k]  # PosOrnKeypointDistFunct
         kps.append(d)
     dof = 7
     lim = inp["limits"]

@@ -102,7 +102,8 @@ def test_tutorial_traces_on_gpu(ctx, name, idx, hip_path):
 
 @pytest.mark.parametrize("cfg_name,B,nb_iter,limits", [("C2", 256, 20, "inactive"), ("C3r", 128, 12, "inactive"), ("C3", 96, 12, "inactive"),
                                                        ("C2nd", 64, 10, "inactive"), ("C4t1", 64, 12, "inactive"), ("C4", 48, 6, "inactive"),
-                                                       ("C2", 64, 12, "urdf"), ("C3", 64, 12, "urdf"), ("C2nd", 32, 8, "urdf")])
+                                                       ("C2", 64, 12, "urdf"), ("C3", 64, 12, "urdf"), ("C2nd", 32, 8, "urdf"),
+                                                       ("C3d", 96, 15, "inactive"), ("C2ndd", 48, 10, "inactive")])  # C3d/C2ndd: PosOrnKeypointDistFunct
 def test_random_batch_vs_oracle(ctx, cfg_name, B, nb_iter, limits):
     """Seeded random batches: final cost within 1e-4 relative of the oracle.
 

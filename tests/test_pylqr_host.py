@@ -97,3 +97,38 @@ def test_kdlrobot_errors_and_no_cpu_fallback(PyLQR):
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError, match="only run on the GPU"):  # FK runs on the device: fail loudly, never on the CPU
             KDLRobot(urdf, "panda_link0", "panda_tip", [0.0] * 7, [0.0] * 7)
+
+
+def test_dist_funct_keypoint(PyLQR):
+    """PosOrnKeypointDistFunct (PosOrnKeypointDistFunct.cpp:13-35): host class against the oracle's restatement, and the
+    dead-zone properties themselves (zero inside the ball / thresholds, residual shrunk by exactly the radius outside)."""
+    import ctypes as C
+    from PyLQR.system import PosOrnKeypoint, PosOrnKeypointDistFunct
+
+    pos, orn = [0.5, 0.1, 0.3], [0.0, 0.92387953, 0.38268343, 0.0]
+    seg = orc.chain_from_urdf(open(os.path.join(GOLDEN, "panda_chain.urdf")).read(), "panda_link0", "panda_tip")
+    rng = np.random.default_rng(3)
+    for radius, th in ((0.05, [0.1, 0.1, 0.1]), (10.0, [10.0, 0.0, 0.3]), (0.0, [0.0, 0.0, 0.0])):
+        s = orc.make_system(seg, orc.SYS_POS_ORN, 1, 100, 0.1, [1e-5] * 7,
+                            [dict(timestep=49, pos=pos, orn=orn, Q=np.eye(6), dist=dict(pos_radius=radius, orn_thresh=th))], [0.1] * 7)
+        plain = PosOrnKeypoint(pos, orn, np.eye(6), 49)
+        kp = PosOrnKeypointDistFunct(pos, orn, np.eye(6), radius, th, 49)
+        assert kp.get_timestep() == 49
+        for _ in range(5):
+            q = rng.uniform(-1, 1, 7)
+            fx, _ = orc.get_fx_jac(s, q)
+            e = np.zeros(6)
+            orc.lib().orc_kp_diff(C.byref(s), C.byref(s.kp[0]), orc._dp(fx), orc._dp(e))
+            got, base = np.asarray(kp.diff(fx)), np.asarray(plain.diff(fx))
+            np.testing.assert_allclose(got, e, atol=1e-14)
+            n = np.linalg.norm(base[:3])
+            if n <= radius:
+                assert np.all(got[:3] == 0)
+            else:
+                np.testing.assert_allclose(np.linalg.norm(got[:3]), n - radius, atol=1e-13)
+                np.testing.assert_allclose(np.cross(got[:3], base[:3]), 0, atol=1e-13)  # same direction
+            for i in range(3):
+                v = base[3 + i]
+                assert got[3 + i] == (0.0 if abs(v) <= th[i] else v - np.sign(v) * th[i])
+    with pytest.raises(RuntimeError):
+        PosOrnKeypointDistFunct(pos, orn, np.eye(6), 0.1, [0.1, 0.1], 49)
