@@ -29,7 +29,7 @@ EXPORTS = [
     "ilqr_problem_get_iters", "ilqr_problem_get_status", "ilqr_problem_get_lambda", "ilqr_problem_get_trace",
     "ilqr_problem_get_X_dev", "ilqr_problem_get_U_dev", "ilqr_problem_get_cost_dev", "ilqr_fk_batch",
     "ilqr_profile_enable", "ilqr_profile_reset", "ilqr_profile_get", "ilqr_chain_from_urdf", "ilqr_urdf_last_error",
-    "ilqr_problem_reset_multipliers",
+    "ilqr_problem_reset_multipliers", "ilqr_problem_warm_start", "ilqr_problem_track", "ilqr_problem_track_dev",
 ]
 
 
@@ -104,6 +104,9 @@ def load():
         getattr(L, n).argtypes = [vp, vp]
     L.ilqr_problem_set_constraints.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp]
     L.ilqr_problem_reset_multipliers.argtypes = [vp]
+    L.ilqr_problem_warm_start.argtypes = [vp, C.c_int]
+    L.ilqr_problem_track.argtypes = [vp, C.c_int, dp, C.c_int, dp]
+    L.ilqr_problem_track_dev.argtypes = [vp, C.c_int, vp, C.c_int, vp]
     L.ilqr_solve_recursive.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.ilqr_solve_al.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int]
     L.ilqr_solve_batch_cp.argtypes = [vp, dp, C.c_int, C.c_int, C.c_int]
@@ -359,6 +362,16 @@ class BatchProblem:
 
     def get_cost_dev(self, ptr):
         self.ctx.check(self.L.ilqr_problem_get_cost_dev(self.h, ptr))
+
+    # ---- receding horizon / tracking
+    def warm_start(self, shift: int = 0):
+        self.ctx.check(self.L.ilqr_problem_warm_start(self.h, int(shift)))
+
+    def track(self, k: int, x_meas, with_feedforward: bool = False):
+        x = _f64(x_meas, (self.B, self.dims.n_x))
+        u = np.empty((self.B, self.dims.n_u))
+        self.ctx.check(self.L.ilqr_problem_track(self.h, int(k), _dp(x), int(bool(with_feedforward)), _dp(u)))
+        return u
 
     def close(self):
         if self.h:

@@ -598,6 +598,48 @@ static int get_gains(ilqr_problem* p, double* K, double* d) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
+// ---- receding horizon / tracking
+extern "C" int ilqr_problem_warm_start(ilqr_problem* p, int shift) {
+    if (!p) return 1;
+    ilqr_ctx* c = p->ctx;
+    if (!p->has_state || !p->has_controls) return fail(c, "warm start needs a previous solve (set_init_state, set_controls, solve)");
+    if (shift < 0 || shift >= p->T) return fail(c, "shift must be in [0, T)");
+    HIPCHK(c, hipSetDevice(c->device));
+    launch_warm_start(p->bufs, const_cast<double*>(p->bufs.U0), const_cast<double*>(p->bufs.q0), const_cast<double*>(p->bufs.dq0), shift, p->B, p->T,
+                      p->dims.n_x, p->dims.n_u, p->desc.nb_deriv, c->stream);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+static int track(ilqr_problem* p, int k, const double* x_meas, int with_ff, double* u_out, bool dev) {
+    if (!p) return 1;
+    ilqr_ctx* c = p->ctx;
+    if (!x_meas || !u_out) return fail(c, "null pointer");
+    if (k < 0 || k >= p->T - 1) return fail(c, "timestep outside [0, T-2]");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t nxb = (size_t)p->B * p->dims.n_x, nub = (size_t)p->B * p->dims.n_u;
+    const double* xs = x_meas;
+    double* us = u_out;
+    if (!dev) {
+        if (ensure_staging(p, nxb + nub)) return 1;
+        HIPCHK(c, hipMemcpyAsync(p->staging, x_meas, nxb * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        xs = p->staging;
+        us = p->staging + nxb;
+    }
+    launch_track(p->bufs, xs, k, with_ff, us, p->B, p->dims.n_x, p->dims.n_u, c->stream);
+    HIPCHK(c, hipGetLastError());
+    if (!dev) {
+        HIPCHK(c, hipMemcpyAsync(u_out, us, nub * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+extern "C" int ilqr_problem_track(ilqr_problem* p, int k, const double* x_meas, int with_feedforward, double* u_out) {
+    return track(p, k, x_meas, with_feedforward, u_out, false);
+}
+extern "C" int ilqr_problem_track_dev(ilqr_problem* p, int k, const double* x_meas, int with_feedforward, double* u_out) {
+    return track(p, k, x_meas, with_feedforward, u_out, true);
+}
+
 extern "C" int ilqr_problem_get_K(ilqr_problem* p, double* K) { return get_gains(p, K, nullptr); }
 extern "C" int ilqr_problem_get_d(ilqr_problem* p, double* d) { return get_gains(p, nullptr, d); }
 extern "C" int ilqr_problem_get_cost(ilqr_problem* p, double* cost) { return p ? download(p, GET_PLAIN, p->bufs.cost, nullptr, cost, false, 1) : 1; }

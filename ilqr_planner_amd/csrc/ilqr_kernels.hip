@@ -365,6 +365,44 @@ __global__ void k_get_gains(const double* __restrict__ kd, const double* __restr
     }
 }
 
+// Receding-horizon warm start: the next solve starts from the accepted plan shifted by `shift` timesteps --
+// U0[k] = U[min(k + shift, T-2)], q0 (dq0) = the joint part of x_{shift}.  One lane per (instance, timestep).
+__global__ void k_warm_start(Bufs a, double* __restrict__ U0, double* __restrict__ q0, double* __restrict__ dq0, int shift, int nx, int nu, int nd) {
+    const DevDesc& d = *a.desc;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+    if (b >= d.B) return;
+    const int Bp = d.Bp, T = d.T;
+    const int cur = a.cur[b];
+    const int ks = (k + shift < T - 1) ? k + shift : T - 2;
+    for (int i = 0; i < nu; i++) AT(U0, k * nu + i, b) = AT(a.U[cur], ks * nu + i, b);
+    if (k == 0 && shift > 0) {
+        const int kx = shift < T ? shift : T - 1;
+        for (int i = 0; i < DOF; i++) {
+            AT(q0, i, b) = AT(a.X[cur], kx * nx + i, b);
+            if (nd == 2) AT(dq0, i, b) = AT(a.X[cur], kx * nx + DOF + i, b);
+        }
+    }
+}
+
+// Tracking law of the tutorials (POS_ORN_SYS.ipynb cell 7): u = ubar_k + K_k (x - xbar_k) [+ alpha d_k] for a measured state
+// per instance; natural layouts x_meas[B][NX], u_out[B][NU].  One lane per instance.
+__global__ void k_track(Bufs a, const double* __restrict__ x_meas, int k, int with_ff, double* __restrict__ u_out, int nx, int nu) {
+    const DevDesc& d = *a.desc;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= d.B) return;
+    const int Bp = d.Bp;
+    const int cur = a.cur[b];
+    const int rowp = kd_rowp(nx), rs = nu * rowp;
+    const double* rec = KD_REC(a.KD, Bp, rs, k, b);
+    const double sc = (a.iters[b] > 0) ? a.alpha[b] : 1.0;
+    for (int i = 0; i < nu; i++) {
+        double s = AT(a.U[cur], k * nu + i, b);
+        for (int j = 0; j < nx; j++) s += rec[i * rowp + j] * (x_meas[(size_t)b * nx + j] - AT(a.X[cur], k * nx + j, b));
+        if (with_ff) s += sc * rec[i * rowp + nx];
+        u_out[(size_t)b * nu + i] = s;
+    }
+}
+
 // f(X) for every (instance, timestep): one lane per pair (tuple<1> of ILQRRecursive::solve)
 template <class S>
 __global__ void k_fx_all(Bufs a, double* __restrict__ out /* natural [B][T][NF] */) {
@@ -451,6 +489,12 @@ void launch_from_soa_scaled(const double* src, const double* alpha, const int* i
 void launch_get_gains(const double* kd, const double* alpha, const int* iters, double* K_out, double* d_out, int B, int Bp, int T1, int nu, int nx,
                        hipStream_t st) {
     hipLaunchKernelGGL(k_get_gains, dim3((B + 63) / 64, T1), dim3(64), 0, st, kd, alpha, iters, K_out, d_out, B, Bp, T1, nu, nx);
+}
+void launch_warm_start(const Bufs& a, double* U0, double* q0, double* dq0, int shift, int B, int T, int nx, int nu, int nd, hipStream_t st) {
+    hipLaunchKernelGGL(k_warm_start, dim3((B + 63) / 64, T - 1), dim3(64), 0, st, a, U0, q0, dq0, shift, nx, nu, nd);
+}
+void launch_track(const Bufs& a, const double* x_meas, int k, int with_ff, double* u_out, int B, int nx, int nu, hipStream_t st) {
+    hipLaunchKernelGGL(k_track, dim3((B + 63) / 64), dim3(64), 0, st, a, x_meas, k, with_ff, u_out, nx, nu);
 }
 void launch_fk_batch(const DevDesc* dd, int n, const double* q, double* pos, double* quat, double* jac, hipStream_t st) {
     hipLaunchKernelGGL(k_fk_batch, dim3((n + 63) / 64), dim3(64), 0, st, dd, n, q, pos, quat, jac);

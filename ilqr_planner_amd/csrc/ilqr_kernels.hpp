@@ -80,6 +80,8 @@ void launch_from_soa(const double* src, double* dst, int B, int Bp, int rows, hi
 void launch_from_soa_cur(const double* s0, const double* s1, const int* cur, double* dst, int B, int Bp, int rows, hipStream_t st);
 void launch_from_soa_scaled(const double* src, const double* alpha, const int* iters, double* dst, int B, int Bp, int rows, hipStream_t st);
 void launch_get_gains(const double* kd, const double* alpha, const int* iters, double* K_out, double* d_out, int B, int Bp, int T1, int nu, int nx, hipStream_t st);
+void launch_warm_start(const Bufs& a, double* U0, double* q0, double* dq0, int shift, int B, int T, int nx, int nu, int nd, hipStream_t st);
+void launch_track(const Bufs& a, const double* x_meas, int k, int with_ff, double* u_out, int B, int nx, int nu, hipStream_t st);
 void launch_fk_batch(const DevDesc* dd, int n, const double* q, double* pos, double* quat, double* jac, hipStream_t st);
 
 }  // namespace ilqr

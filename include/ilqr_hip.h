@@ -170,6 +170,16 @@ int ilqr_problem_get_X_dev(ilqr_problem* p, double* X);
 int ilqr_problem_get_U_dev(ilqr_problem* p, double* U);
 int ilqr_problem_get_cost_dev(ilqr_problem* p, double* cost);
 
+/* ---- receding horizon and tracking (the uses of the gains the tutorials mention, POS_ORN_SYS.ipynb cell 7; no reference
+ * function: ILQRRecursive::solve returns K, k and the caller replays them) -------------------------------------- */
+/* The next solve starts from the accepted plan shifted by `shift` timesteps: U0[k] = U[min(k+shift, T-2)] and, for
+ * shift > 0, q0 (dq0) = joint part of x_shift -- MPC-style re-planning of the whole batch without leaving HBM. */
+int ilqr_problem_warm_start(ilqr_problem* p, int shift);
+/* u = ubar_k + K_k (x_meas - xbar_k) [+ alpha d_k if with_feedforward] for every instance:
+ * x_meas[B][n_x] -> u_out[B][n_u]; K_k, d_k = the gains ilqr_problem_get_K / get_d return. */
+int ilqr_problem_track(ilqr_problem* p, int k, const double* x_meas, int with_feedforward, double* u_out);
+int ilqr_problem_track_dev(ilqr_problem* p, int k, const double* x_meas, int with_feedforward, double* u_out);
+
 /* ---- stand-alone batched kinematics: KDLRobot::updateKinematics for n configurations ---------------------- */
 /* (src/sim/KDLRobot.cpp:83-115): q[n][dof] (dq[n][dof] or NULL) -> pos[n][3], quat[n][4] (w,x,y,z), jac[n][6][dof];
  * any output may be NULL.  Host pointers. */

@@ -263,3 +263,43 @@ def test_error_paths(ctx):
     d2.kp_timestep[1] = d2.kp_timestep[0]
     with pytest.raises(RuntimeError, match="ascending"):
         capi.BatchProblem(ctx, d2, 4)
+
+
+def test_warm_start_and_tracking(ctx):
+    """Receding-horizon warm start and the tracking law against their definitions."""
+    from ilqr_planner_amd import workloads
+
+    cfg = workloads.config("C2")
+    B, nb_iter = 16, 6
+    desc, inp = workloads.make_batch(ctx, cfg, B=B, seed=21)
+    p = workloads.load_batch(ctx, desc, inp, B)
+    p.solve_recursive(nb_iter, True, False)
+    X, U, K, d, cost = p.X(), p.U(), p.K(), p.d(), p.cost()
+    # tracking: at the nominal state the law returns the nominal control; off it, the gains act on the deviation
+    k = 17
+    np.testing.assert_allclose(p.track(k, X[:, k]), U[:, k], rtol=0, atol=1e-14)
+    rng = np.random.default_rng(0)
+    dx = 1e-2 * rng.standard_normal(X[:, k].shape)
+    want = U[:, k] + np.einsum("bij,bj->bi", K[:, k], dx)
+    np.testing.assert_allclose(p.track(k, X[:, k] + dx), want, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(p.track(k, X[:, k] + dx, True), want + d[:, k], rtol=1e-12, atol=1e-12)
+    # warm start without shift: a 0-iteration solve re-rolls the accepted controls and reproduces the cost
+    p.warm_start(0)
+    p.solve_recursive(0, True, False)
+    np.testing.assert_allclose(p.cost(), cost, rtol=1e-12)
+    np.testing.assert_allclose(p.U(), U, rtol=0, atol=0)
+    Xr = p.X()  # the re-rolled trajectory (equal to X up to rounding: X came out of the line-search blend)
+    np.testing.assert_allclose(Xr, X, rtol=0, atol=1e-12)
+    # shifted: the plan moves up by 5 steps, the tail repeats the last control, the start is x_5
+    p.warm_start(5)
+    p.solve_recursive(0, True, False)
+    U2, X2 = p.U(), p.X()
+    np.testing.assert_array_equal(U2[:, :-5], U[:, 5:])
+    np.testing.assert_array_equal(U2[:, -5:], np.repeat(U[:, -1:], 5, axis=1))
+    np.testing.assert_array_equal(X2[:, 0], Xr[:, 5])
+    # and re-planning from there improves on the shifted plan
+    c0 = p.cost()
+    p.warm_start(0)
+    p.solve_recursive(4, True, False)
+    assert np.all(p.cost() <= c0 + 1e-12)
+    p.close()
