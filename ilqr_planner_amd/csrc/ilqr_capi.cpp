@@ -310,6 +310,8 @@ extern "C" int ilqr_problem_create(ilqr_ctx* c, const ilqr_problem_desc* d, int 
     rc |= dalloc(p, &b.lsc, (size_t)16 * Bp);
     rc |= dalloc(p, &b.dun, Bp);
     rc |= dalloc(p, &b.kpdev, (size_t)(d->n_kp > 0 ? d->n_kp : 1) * (NX + NU) * Bp);
+    rc |= dalloc(p, &b.kpx, (size_t)(d->n_kp > 0 ? d->n_kp : 1) * 16 * (NX + NU) * Bp);
+    rc |= dalloc(p, &b.dunA, (size_t)16 * Bp);
     rc |= dalloc(p, &b.kpd, (size_t)(d->n_kp > 0 ? d->n_kp : 1) * (NX + NX * NX) * Bp);
     if (rc) { ilqr_problem_destroy(p); return 1; }
     b.U0 = U0; b.q0 = q0; b.dq0 = dq0; b.kp_tg = tg; b.desc = p->ddesc;

@@ -30,6 +30,8 @@ struct Bufs {
     double* lsc;    // [16][Bp] limit cost of the alpha = 1 rollout blended to every step size (k_forward_w32 -> k_select)
     double* dun;    // [Bp] sum_k ||du_k(1)|| of that rollout
     double* kpdev;  // [n_kp][NX+NU][Bp] deviation (dx, du) of that rollout at the keypoint steps
+    double* kpx;    // [n_kp][16][NX+NU][Bp] state | control of every alpha's rollout at the keypoint steps (k_forward_tile -> k_select_x)
+    double* dunA;   // [16][Bp] sum_k ||du_k|| of every alpha's rollout
     double* cost_trace;   // [nb_iter][Bp] or null
     double* alpha_trace;  // [nb_iter][Bp] or null
     // augmented Lagrangian (shared constraint rows, per-instance multipliers)

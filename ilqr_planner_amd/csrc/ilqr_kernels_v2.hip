@@ -73,7 +73,6 @@ __global__ __launch_bounds__(256) void k_forward_tile(Bufs a, FwdArgs f) {
     constexpr int NX = S::NX, NU = S::NU, NK = NU * NX;
     constexpr int NC = NK + NU + NX + NU;          // doubles per instance-step: K | d | xbar | ubar
     constexpr int NO = NX + NU;                    // doubles written per instance-step: x | u
-    constexpr int NLD = (NC * 16 + 255) / 256;     // cooperative loads per thread per step
     constexpr int PF = 4;                          // prefetch distance in timesteps
     __shared__ double s_in[2][NC][16];
     __shared__ double s_out[2][NO][16];
@@ -111,38 +110,51 @@ __global__ __launch_bounds__(256) void k_forward_tile(Bufs a, FwdArgs f) {
     const int n_kp = d.n_kp;
     int kp_next = (n_kp > 0) ? d.kp_t[0] : -1;
 
-    // loader role: this thread always fetches for instance (tid & 15), components (tid >> 4) + 16 j
+    // loader.  Gains: the records of the tile's 16 instances at one timestep are ONE contiguous run of 16 RS doubles; thread t
+    // fetches flat elements t + 256 q (fully coalesced) and knows where each lands in the [component][instance] LDS image.
+    // xbar | ubar: component (tid >> 4) + 16 j of instance tid & 15 (16 instances of a row = one 128-byte line).
+    // Every load is unconditional (timesteps beyond the end re-read the last one): see ilqr_kernels_coop.hip on vmcnt.
+    constexpr int ROWP = kd_rowp(NX), RS = NU * ROWP;
+    constexpr int NLG = (16 * RS + 255) / 256;           // gain loads per thread per step
+    constexpr int NLX = ((NX + NU) * 16 + 255) / 256;    // xbar/ubar loads per thread per step
+    constexpr int NLD = NLG + NLX;
     const int li = tid & 15, lb = b0 + li, lc0 = tid >> 4;
     const int lcur = a.cur[lb];
     const double* Xc = a.X[lcur];
     const double* Uc = a.U[lcur];
-    // per-thread load slots: address of step 0 and byte stride per timestep, resolved once (K | d | xbar | ubar regions)
-    const double* lptr[NLD];
-    size_t lstep[NLD];
-    constexpr int ROWP = kd_rowp(NX), RS = NU * ROWP;
-    UNR for (int j = 0; j < NLD; j++) {
-        const int c = lc0 + 16 * j;
-        if (c >= NK + NU + NX) { lptr[j] = Uc + (size_t)(c - NK - NU - NX) * Bp + lb; lstep[j] = (size_t)NU * Bp; }
-        else if (c >= NK + NU) { lptr[j] = Xc + (size_t)(c - NK - NU) * Bp + lb; lstep[j] = (size_t)NX * Bp; }
-        else {  // gain record of instance lb: K[i][jj] at i*ROWP+jj, d[i] at i*ROWP+NX
-            const int off = (c >= NK) ? (c - NK) * ROWP + NX : (c / NX) * ROWP + (c % NX);
-            lptr[j] = a.KD + (size_t)lb * RS + off;
-            lstep[j] = (size_t)Bp * RS;
-        }
+    const double* gbase = KD_REC(a.KD, Bp, RS, 0, b0);
+    const size_t gstep = (size_t)Bp * RS;
+    int goff[NLG], gdst[NLG];  // flat source offset (clamped into the run) and LDS destination (-1: padding / out of range)
+    UNR for (int q = 0; q < NLG; q++) {
+        const int fl = tid + 256 * q;
+        const bool in = fl < 16 * RS;
+        const int flc = in ? fl : 0;
+        const int inst = flc / RS, w = flc % RS, i = w / ROWP, jj = w % ROWP;
+        goff[q] = flc;
+        gdst[q] = !in ? -1 : (jj < NX ? (i * NX + jj) * 16 + inst : (jj == NX ? (NK + i) * 16 + inst : -1));
+    }
+    const double* xptr[NLX];
+    size_t xstep[NLX];
+    int xkmax[NLX], xdst[NLX];
+    UNR for (int j = 0; j < NLX; j++) {
+        const int c = lc0 + 16 * j;          // 0 .. NX+NU-1 valid
+        const bool in = c < NX + NU;
+        const int cc = in ? c : 0;
+        if (cc < NX) { xptr[j] = Xc + (size_t)cc * Bp + lb; xstep[j] = (size_t)NX * Bp; xkmax[j] = T - 1; }
+        else { xptr[j] = Uc + (size_t)(cc - NX) * Bp + lb; xstep[j] = (size_t)NU * Bp; xkmax[j] = T - 2; }
+        xdst[j] = in ? (NK + NU + cc) * 16 + li : -1;
     }
     auto load_step = [&](int k, double* r) {
-        if (k < T - 1) {  // uniform
-            UNR for (int j = 0; j < NLD; j++) {
-                r[j] = 0;
-                if (lc0 + 16 * j < NC) r[j] = lptr[j][(size_t)k * lstep[j]];
-            }
-        }
+        const int kg = k < T - 1 ? k : T - 2;
+        UNR for (int q = 0; q < NLG; q++) r[q] = gbase[(size_t)kg * gstep + goff[q]];
+        UNR for (int j = 0; j < NLX; j++) r[NLG + j] = xptr[j][(size_t)(k < xkmax[j] ? k : xkmax[j]) * xstep[j]];
     };
     auto stage_step = [&](int buf, const double* r) {
-        UNR for (int j = 0; j < NLD; j++) {
-            const int c = lc0 + 16 * j;
-            if (c < NC) s_in[buf][c][li] = r[j];
-        }
+        double* dst = &s_in[buf][0][0];
+        UNR for (int q = 0; q < NLG; q++)
+            if (gdst[q] >= 0) dst[gdst[q]] = r[q];
+        UNR for (int j = 0; j < NLX; j++)
+            if (xdst[j] >= 0) dst[xdst[j]] = r[NLG + j];
     };
     // output stage: thread t stores component (t >> 4) + 16 j of instance t & 15
     constexpr int NST = (NO + 15) / 16;
@@ -202,15 +214,16 @@ __global__ __launch_bounds__(256) void k_forward_tile(Bufs a, FwdArgs f) {
                         UNR for (int i = 0; i < NX; i++) s_out[buf][i][il] = x[i];
                         UNR for (int i = 0; i < NU; i++) s_out[buf][NX + i][il] = u[i];
                     }
-                    if (k == kp_next) {  // keypoint step (rare): task cost out of line
-                        double xt[NX], ut[NU];
-                        UNR for (int i = 0; i < NX; i++) xt[i] = x[i];
-                        UNR for (int i = 0; i < NU; i++) ut[i] = u[i];
-                        newCost += kp_cost_call<S>(&d, a.kp_tg, Bp, b, kpi, xt, ut);
+                    if (k == kp_next) {  // keypoint step (rare): hand (x, u) of this alpha to k_select_x -- the FK stays out of this kernel
+                        if (!APPLY) {
+                            double* o = a.kpx + ((size_t)kpi * 16 + ai) * (NX + NU) * Bp;
+                            UNR for (int i = 0; i < NX; i++) AT(o, i, b) = x[i];
+                            UNR for (int i = 0; i < NU; i++) AT(o, NX + i, b) = u[i];
+                        }
                         kpi++;
                         kp_next = (kpi < n_kp) ? d.kp_t[kpi] : -1;
                     }
-                    newCost += lim.cost(x);
+                    if (!APPLY) newCost += lim.cost(x);
                     // dynamics step (SimulationInterface.cpp:19-31)
                     const double dts = S::TM ? u[NU - 1] : 0.0;
                     const double dt = S::TM ? dts * dts : dt_fixed;
@@ -236,13 +249,11 @@ __global__ __launch_bounds__(256) void k_forward_tile(Bufs a, FwdArgs f) {
         const int buf = nsteps & 1;
         if (part) {
             if (writer) { UNR for (int i = 0; i < NX; i++) s_out[buf][i][il] = x[i]; }
-            if (kp_next == T - 1) {
-                double xt[NX], zu[NU];
-                UNR for (int i = 0; i < NX; i++) xt[i] = x[i];
-                UNR for (int i = 0; i < NU; i++) zu[i] = 0;
-                newCost += kp_cost_call<S>(&d, a.kp_tg, Bp, b, kpi, xt, zu);
+            if (!APPLY && kp_next == T - 1) {
+                double* o = a.kpx + ((size_t)kpi * 16 + ai) * (NX + NU) * Bp;
+                UNR for (int i = 0; i < NX; i++) AT(o, i, b) = x[i];
             }
-            newCost += lim.cost(x);
+            if (!APPLY) newCost += lim.cost(x);
         }
         lds_barrier();
         store_step(T - 1, buf);
@@ -255,31 +266,63 @@ __global__ __launch_bounds__(256) void k_forward_tile(Bufs a, FwdArgs f) {
         }
         return;
     }
-    // ---- winner of the line search: first alpha with !(cost >= cost0 || isnan(cost)), else the last one tried
-    const bool ok = part && !((newCost >= cost0) || isnan(newCost));
-    const unsigned long long bal = __ballot(ok ? 1 : 0);
-    const int lane = tid & 63, g0 = lane & ~15;
-    const unsigned grp = (unsigned)((bal >> g0) & 0xFFFFull);
-    const int w = grp ? (__ffs((int)grp) - 1) : (f.n_alpha - 1);
-    const double wcost = __shfl(newCost, g0 + w);
-    const double wdun = __shfl(dun, g0 + w);
-    if (part && ai == 0) {  // bookkeeping by lane 0 of every active instance
-        const double walpha = ldexp(1.0, -w);
-        const int pr = a.pred[b] < f.n_alpha ? a.pred[b] : f.n_alpha - 1;
-        a.cost[b] = wcost;
-        a.alpha[b] = walpha;
-        a.iters[b] = f.it + 1;
-        a.status[b] = (isfinite(wcost) ? 0 : 1) | ((walpha <= d.alpha_floor) ? 2 : 0);
-        if (a.cost_trace) {
-            a.cost_trace[(size_t)f.it * Bp + b] = wcost;
-            a.alpha_trace[(size_t)f.it * Bp + b] = walpha;
+    // ---- limit cost and sum ||du|| of this alpha; the task cost and the decision are k_select_x's
+    if (part) {
+        AT(a.lsc, ai, b) = newCost;
+        AT(a.dunA, ai, b) = dun;
+    }
+}
+
+// Line-search decision for the alpha-parallel rollouts of k_forward_tile, one lane per (instance, alpha): task cost at the
+// keypoints from the exported (x, u) + the limit cost; the first alpha whose cost is below the current one and not NaN wins,
+// else the last one tried (ILQRRecursive.cpp:101-155).  If the winner is the lane that wrote its trajectory speculatively
+// (the predicted winner) the buffers flip here, otherwise `pend` asks the APPLY pass to re-roll it.
+template <class S>
+__global__ __launch_bounds__(64) void k_select_x(Bufs a, FwdArgs f) {
+    constexpr int NX = S::NX, NU = S::NU;
+    const DevDesc& d = *a.desc;
+    const int lane = threadIdx.x, gi = lane >> 4, ai = lane & 15;
+    const int b = blockIdx.x * 4 + gi;
+    const int Bp = d.Bp, T = d.T, B = d.B;
+    const bool inst_ok = (b < B) && (a.active[b < B ? b : 0] != 0);
+    const int bb = (b < B) ? b : 0;
+    const bool part = inst_ok && ai < f.n_alpha;
+    double c = 0;
+    if (part) {
+        for (int kpi = 0; kpi < d.n_kp; kpi++) {
+            const int k = d.kp_t[kpi];
+            const double* o = a.kpx + ((size_t)kpi * 16 + ai) * (NX + NU) * Bp;
+            double xt[NX], ut[NU], tg[S::NF];
+            UNR for (int i = 0; i < NX; i++) xt[i] = AT(o, i, bb);
+            UNR for (int i = 0; i < NU; i++) ut[i] = (k < T - 1) ? AT(o, NX + i, bb) : 0.0;
+            UNR for (int i = 0; i < S::NF; i++) tg[i] = AT(a.kp_tg, kpi * S::NF + i, bb);
+            c += kp_cost<S>(d, kpi, tg, xt, ut);
         }
-        if (w == pr) a.cur[b] = 1 - a.cur[b];  // the speculatively written trajectory is the accepted one
-        else a.pend[b] = w + 1;
-        a.pred[b] = w;
+        c += AT(a.lsc, ai, bb);
+    }
+    const double cost0 = a.cost[bb];
+    const bool ok = part && !((c >= cost0) || isnan(c));
+    const unsigned m16 = (unsigned)((__ballot(ok ? 1 : 0) >> (gi * 16)) & 0xffffull);
+    const int w = m16 ? (__ffs(m16) - 1) : (f.n_alpha - 1);
+    const double wcost = __shfl(c, gi * 16 + w);
+    if (inst_ok && ai == 0) {
+        const double walpha = ldexp(1.0, -w);
+        const double wdun = AT(a.dunA, w, bb);
+        const int pr = a.pred[bb] < f.n_alpha ? a.pred[bb] : f.n_alpha - 1;
+        a.cost[bb] = wcost;
+        a.alpha[bb] = walpha;
+        a.iters[bb] = f.it + 1;
+        a.status[bb] = (isfinite(wcost) ? 0 : 1) | ((walpha <= d.alpha_floor) ? 2 : 0);
+        if (a.cost_trace) {
+            a.cost_trace[(size_t)f.it * Bp + bb] = wcost;
+            a.alpha_trace[(size_t)f.it * Bp + bb] = walpha;
+        }
+        if (w == pr) a.cur[bb] = 1 - a.cur[bb];  // the speculatively written trajectory is the accepted one
+        else a.pend[bb] = w + 1;
+        a.pred[bb] = w;
         bool stop = f.early_stop && (walpha * sqrt(wdun) < d.stop_tol);
         if (!f.al) stop = stop && (wcost < 1e-3);  // ILQRRecursive.cpp:174 vs AL-ILQR.cpp:225
-        if (stop) a.active[b] = 0;
+        if (stop) a.active[bb] = 0;
     }
 }
 
@@ -543,6 +586,7 @@ static void launch_v2_kernel(int which, const Bufs& a, int B, int T, hipStream_t
     switch (which) {
         case KER_FWD_SPEC:
             hipLaunchKernelGGL((k_forward_tile<S, false>), gridT, blockT, 0, st, a, f);
+            hipLaunchKernelGGL((k_select_x<S>), dim3((B + 3) / 4), dim3(64), 0, st, a, f);
             break;
         case KER_FWD_APPLY:
             hipLaunchKernelGGL((k_forward_tile<S, true>), gridT, blockT, 0, st, a, f);
