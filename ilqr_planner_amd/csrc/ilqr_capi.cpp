@@ -473,7 +473,8 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
     const bool fwd_lin = fwd_rows && !(fwd_env && !std::strcmp(fwd_env, "rows"));  // linear line search (PosOrn systems)
     const bool fwd_wave = fwd_lin && forward_wave_supported(kind, nd, n_alpha);  // 32 lanes per instance + k_select
     const bool bwd_si = (path == 2) && backward_si_supported(kind, nd, al, p->bufs.m, p->bufs.per_step, p->con_state_only);
-    const bool bwd_gen = (path == 2) && !bwd_si && backward_gen_supported(kind, nd, al, p->bufs.m);  // wave per instance, any system
+    const bool bwd_mfma = (path == 2) && !bwd_si && backward_mfma_supported(kind, nd, al, p->bufs.m);  // wave per instance, f64 matrix cores
+    const bool bwd_gen = (path == 2) && !bwd_si && !bwd_mfma && backward_gen_supported(kind, nd, al, p->bufs.m);  // same, VALU + LDS products
     FwdArgs f;
     std::memset(&f, 0, sizeof(f));
     f.line_search = line_search; f.early_stop = early_stop; f.nb_iter = nb_iter; f.penalty_roll = penalty; f.n_alpha = n_alpha; f.al = al ? 1 : 0; f.n_kp = p->desc.n_kp;
@@ -493,12 +494,13 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
     HIPCHK(c, hipGetLastError());
     for (int it = 0; it < nb_iter; it++) {
         {
-            if (bwd_si || bwd_gen) {
+            if (bwd_si || bwd_gen || bwd_mfma) {
                 ProfScope ps(c, ILQR_PROF_OTHER);
                 launch_solver_v2(kind, nd, KER_KP_DERIVS, al, p->bufs, p->B, p->T, c->stream, f);
             }
             ProfScope ps(c, ILQR_PROF_BACKWARD);
             if (bwd_si) launch_solver_v2(kind, nd, KER_BACKWARD_SI, al, p->bufs, p->B, p->T, c->stream, f);
+            else if (bwd_mfma) launch_backward_mfma(kind, nd, al, p->bufs, p->B, c->stream);
             else if (bwd_gen) launch_backward_gen(kind, nd, al, p->bufs, p->B, c->stream);
             else launch_solver(kind, nd, KER_BACKWARD, al, p->bufs, p->B, c->stream, f);
         }

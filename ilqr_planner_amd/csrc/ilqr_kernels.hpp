@@ -66,6 +66,8 @@ void launch_solver(int kind, int nd, int which, bool al, const Bufs& a, int B, h
 bool backward_si_supported(int kind, int nd, bool al, int m, int per_step, bool con_state_only);
 void launch_solver_v2(int kind, int nd, int which, bool al, const Bufs& a, int B, int T, hipStream_t st, const FwdArgs& f);
 void launch_backward_si_coop(bool al, const Bufs& a, int B, hipStream_t st);
+bool backward_mfma_supported(int kind, int nd, bool al, int m);
+void launch_backward_mfma(int kind, int nd, bool al, const Bufs& a, int B, hipStream_t st);  // needs KER_KP_DERIVS first
 bool backward_gen_supported(int kind, int nd, bool al, int m);
 void launch_backward_gen(int kind, int nd, bool al, const Bufs& a, int B, hipStream_t st);  // needs KER_KP_DERIVS first
 bool forward_rows_supported(int kind, int nd, int n_alpha);

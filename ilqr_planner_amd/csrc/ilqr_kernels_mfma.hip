@@ -1,0 +1,366 @@
+// ilqr_kernels_mfma.hip -- wave-per-instance backward Riccati sweep with the dense products on the f64 matrix cores
+//
+// Same step as k_backward_gen (ilqr_kernels_gen.hip; ILQRRecursive.cpp:68-97, AL terms AL-ILQR.cpp:110-134), re-mapped so that
+// the three genuinely dense products of a step run as v_mfma_f64_16x16x4_f64 and chain through registers.  Everything is
+// carried with ONE extra "affine" column NX (all systems have n_x <= 15):
+//     Qux~ = [Qux | Qu]   K~ = [K | d] = Quu_inv Qux~   T1~ = Quu K~ + Qux~ = [Quu K + Qux | Quu d + Qu]
+//     P~'  = [Qxx | Qx] + K~^T T1~ + [Qxu ; 0] K~       = [P' | p']   (row NX and rows/columns beyond are never read)
+// Lane l = (h = l >> 4, c = l & 15).  The f64 MFMA takes A[i = c][k = h], B[k = h][j = c] and returns D[row = h + 4 r][col = c]
+// in register r -- so the D registers r = 0, 1 of a product ARE the A/B operands of k-step 0, 1 of the next one:
+//     K~  = S (LDS)  x Qux~ (registers, "U-map": lane owns control rows h, h+4 of column c)
+//     T1~ = Quu (LDS) x K~ (D registers of the first product) + Qux~
+//     P~' = K~^T T1~ (both D registers) + Qxu (registers: the U-map transposed) x K~ + [Qxx | Qx] ("P-map": rows h+4r, column c)
+// No LDS traffic at all for the products (k_backward_gen spent 250 of its 410 LDS instructions per step there and is bound by
+// LDS bandwidth).  What is left in LDS: P (read entrywise for the structured A^T P A, B^T P, ...), B^T P, the Quu sweep, and
+// the few vectors.  The time column of B needs dot products with P and B^T P: they are split over all 64 lanes and reduced
+// with lane shuffles instead of being walked by the 16 lanes that own the results.
+// MI355X runs f64 MFMA at the vector rate -- the gain is the removed LDS traffic, not FLOPs.
+#include <cstdlib>
+#include <cstring>
+
+#include "ilqr_step.hpp"
+
+namespace ilqr {
+
+#define LDS_ORDER() asm volatile("" ::: "memory")
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double rcp_nr_m(double x) {  // 1/x: v_rcp_f64 + two Newton steps
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    return fma(r, e, r);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp64m(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double oct_sum_m(double v) {  // sum over lanes 8m .. 8m+7, result in all eight
+    v += dpp64m<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp64m<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp64m<0x141>(v);  // row_half_mirror
+    return v;
+}
+__device__ __forceinline__ double row16_sum(double v) {  // sum over the 16 lanes of a DPP row, result in all sixteen
+    v = oct_sum_m(v);
+    v += dpp64m<0x140>(v);  // row_mirror
+    return v;
+}
+__device__ __forceinline__ double cross_rows_sum(double v) {  // sum over lanes c, c+16, c+32, c+48
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_m(double v) { return cross_rows_sum(row16_sum(v)); }
+
+template <class S, bool AL>
+__global__ __launch_bounds__(64) void k_backward_mfma(Bufs a) {
+    constexpr int NX = S::NX, NU = S::NU, ND = S::ND, TM = S::TM;
+    constexpr int PS = 18;  // row stride of sP / sBtP (doubles): rows 16-byte aligned, starts in distinct banks
+    constexpr int TS = 10;  // row stride of the NU x NU matrices
+    constexpr int ROWP = kd_rowp(NX), RS = NU * ROWP;
+    constexpr int MMAX = 16;
+    static_assert(NX <= 15 && NU <= 8, "one affine column next to the state, two k-steps of 4");
+    __shared__ __attribute__((aligned(16))) double sP[16][PS], sBtP[8][PS], sS[8][TS], sQuu[8][TS];
+    __shared__ __attribute__((aligned(16))) double sx[16], su[8], sbc[16], sp[16], slam[MMAX], sIs[MMAX];
+
+    const DevDesc& d = *a.desc;
+    const int l = threadIdx.x, h = l >> 4, c16 = l & 15;
+    const int b = xcd_tile();
+    if (b >= d.B) return;
+    if (!a.active[b]) return;  // wave-uniform: one instance per wave
+    const int Bp = d.Bp, T = d.T;
+    const int cur = a.cur[b];
+    const double* X = a.X[cur];
+    const double* U = a.U[cur];
+    const double reg = d.reg, pen = d.penalty;
+    const int lim_on = d.limits_set;
+    const int m = AL ? a.m : 0;
+
+    // zero the LDS images once: padding rows/columns feed the matrix cores (0 x garbage must not be NaN)
+    for (int i = l; i < 16 * PS; i += 64) (&sP[0][0])[i] = 0;
+    for (int i = l; i < 8 * PS; i += 64) (&sBtP[0][0])[i] = 0;
+    for (int i = l; i < 8 * TS; i += 64) { (&sS[0][0])[i] = 0; (&sQuu[0][0])[i] = 0; }
+    if (l < 16) { sx[l] = 0; sbc[l] = 0; sp[l] = 0; slam[l] = 0; sIs[l] = 0; }
+    if (l < 8) su[l] = 0;
+    LDS_ORDER();
+
+    // ---- lane maps
+    const bool colS = c16 < NX;      // this lane's column is a state column
+    const bool colA = c16 == NX;     // ... the affine column
+    const int cj = colS ? c16 : 0;   // clamped state index of the column
+    int ui[2];
+    bool uv[2];                      // U-map: control rows h, h+4
+    UNR for (int r = 0; r < 2; r++) { uv[r] = (h + 4 * r) < NU; ui[r] = uv[r] ? h + 4 * r : 0; }
+    int pi[4];
+    bool pv[4];                      // P-map: state rows h + 4r
+    UNR for (int r = 0; r < 4; r++) { pv[r] = (h + 4 * r) < NX; pi[r] = pv[r] ? h + 4 * r : 0; }
+    const bool qv = (l >> 3) < NU && (l & 7) < NU;  // Quu map: (row l >> 3, column l & 7)
+    const int qi = qv ? l >> 3 : 0, qj = qv ? l & 7 : 0;
+    const bool isX = l < NX, isU = l < NU;
+    const int vx = isX ? l : 0, vu = isU ? l : 0;
+    auto is_vrow = [](int i) { return ND == 2 && i >= DOF && i < 2 * DOF; };
+
+    // limit parameters of the entries this lane needs: diagonal P-map entries (l_xx) and the affine column (l_x)
+    bool dgl[4];
+    double lmx[4], lmn[4];
+    UNR for (int r = 0; r < 4; r++) {
+        const bool on = pv[r] && (colA || (colS && pi[r] == c16));
+        dgl[r] = on && d.lw[pi[r]] != 0;
+        lmx[r] = d.smax[pi[r]];
+        lmn[r] = d.smin[pi[r]];
+    }
+
+    int kpi = d.n_kp - 1;
+    int kp_next = (kpi >= 0) ? d.kp_t[kpi] : -1;
+    const size_t kpd_stride = (size_t)(NX + NX * NX) * Bp;
+    // [l_xx | l_x] of step k in the P-map (needs sx); keypoint steps come from k_kp_derivs (limits included)
+    auto stage_terms = [&](int k, double* lq) {
+        UNR for (int r = 0; r < 4; r++) lq[r] = 0;
+        if (k == kp_next) {  // uniform
+            const double* src = a.kpd + (size_t)kpi * kpd_stride;
+            UNR for (int r = 0; r < 4; r++) {
+                if (pv[r] && colS) lq[r] = AT(src, NX + pi[r] * NX + c16, b);
+                if (pv[r] && colA) lq[r] = AT(src, pi[r], b);
+            }
+            kpi--;
+            kp_next = (kpi >= 0) ? d.kp_t[kpi] : -1;
+        } else if (lim_on) {
+            UNR for (int r = 0; r < 4; r++)
+                if (dgl[r]) {
+                    const double xi = sx[pi[r]];
+                    if (colA) {  // l_x_i = -L q,  q = limit - x
+                        if (xi > lmx[r]) lq[r] = -pen * (lmx[r] - xi);
+                        else if (xi < lmn[r]) lq[r] = -pen * (lmn[r] - xi);
+                    } else if (xi > lmx[r] || xi < lmn[r]) {
+                        lq[r] = pen * pen;
+                    }
+                }
+        }
+    };
+    {   // terminal values: P = l_xx(x_{T-1}), p = l_x(x_{T-1})
+        const double xv = AT(X, (T - 1) * NX + vx, b);
+        if (isX) sx[vx] = xv;
+        LDS_ORDER();
+        double lq[4];
+        stage_terms(T - 1, lq);
+        UNR for (int r = 0; r < 4; r++) {
+            if (pv[r] && colS) sP[pi[r]][c16] = lq[r];
+            if (pv[r] && colA) sp[pi[r]] = lq[r];
+        }
+        LDS_ORDER();
+    }
+
+    // ---- prefetch ring: x, u (and lambda, I for AL); every load unconditional (see ilqr_kernels_coop.hip)
+    constexpr int PF = 3;
+    const size_t Xstep = (size_t)NX * Bp, Ustep = (size_t)NU * Bp, Lstep = (size_t)m * Bp;
+    const int lr_ = (AL && l < m) ? l : 0;
+    const double* Xp = X + (size_t)vx * Bp + b + (size_t)(T - 2) * Xstep;
+    const double* Up = U + (size_t)vu * Bp + b + (size_t)(T - 2) * Ustep;
+    const double* Lp = AL ? a.lambda + (size_t)lr_ * Bp + b + (size_t)(T - 2) * Lstep : nullptr;
+    const double* Ip = AL ? a.Is + (size_t)lr_ * Bp + b + (size_t)(T - 2) * Lstep : nullptr;
+    double xr[PF], ur[PF], lmr[PF], isr[PF];
+    auto fetch = [&](int slot, int kk) {
+        xr[slot] = *Xp;
+        ur[slot] = *Up;
+        lmr[slot] = isr[slot] = 0;
+        if (AL) { lmr[slot] = *Lp; isr[slot] = *Ip; }
+        if (kk > 0) { Xp -= Xstep; Up -= Ustep; if (AL) { Lp -= Lstep; Ip -= Lstep; } }  // uniform; no load inside
+    };
+    UNR for (int q = 0; q < PF; q++) { fetch(q, T - 2 - q); __builtin_amdgcn_sched_barrier(0); }
+
+    double* Kout = KD_REC(a.KD, Bp, RS, T - 2, b);
+    const ptrdiff_t Kstep = (ptrdiff_t)Bp * RS;
+
+    for (int k0 = T - 2; k0 >= 0; k0 -= PF) {
+      UNR for (int jj = 0; jj < PF; jj++) {
+        const int k = k0 - jj;
+        const double xv = xr[jj], uv_ = ur[jj], lamv = lmr[jj], isv = isr[jj];
+        fetch(jj, k - PF);
+        if (k < 0) continue;  // uniform: dummy step of the last group
+        // ---- 1. x, u, (lambda, I) into LDS; time column of B
+        if (isX) sx[vx] = xv;
+        if (isU) su[vu] = uv_;
+        if (AL && l < m) { slam[l] = lamv; sIs[l] = isv; }
+        LDS_ORDER();
+        const double dts = TM ? su[NU - 1] : 0.0;
+        const double dt = TM ? dts * dts : d.dt;
+        const double hdt2 = dt * dt / 2;
+        const double c1 = (ND == 1) ? dt : hdt2, c2 = dt;  // B = [c1 I ; c2 I] on the joint block
+        if (TM) {
+            double bcv = 0;
+            if (l < DOF) {
+                if (ND == 1) bcv = 2 * dts * su[l];
+                else {
+                    const double dqn = sx[DOF + l] + dt * su[l];  // velocity AFTER the step (PosOrnTimePlannerSys.cpp:176)
+                    bcv = 2 * dts * dqn + 2 * dts * dts * dts * su[l];
+                }
+            } else if (ND == 2 && l < 2 * DOF) {
+                bcv = 2 * dts * su[l - DOF];
+            } else if (l == NX - 1) {
+                bcv = 2 * dts;
+            }
+            if (isX) sbc[vx] = bcv;
+        }
+        double lq[4];
+        stage_terms(k, lq);
+        LDS_ORDER();
+        auto atp = [&](int i, int cc) { return is_vrow(i) ? dt * sP[i - DOF][cc] + sP[i][cc] : sP[i][cc]; };  // (A^T P)[i][cc]
+        // ---- 2. time column: wT[j] = sum_q bc_q P[q][j] (row NU-1 of B^T P), wA[i] = sum_q (A^T P)[i][q] bc_q (column NU-1 of
+        //         Qxu), bp = bc . p; every lane adds 4 terms of the sum for column / row c16, lanes c16 + 16 h' hold the rest
+        double wT = 0, wA = 0, bp = 0;
+        if (TM) {
+            UNR for (int t = 0; t < 4; t++) {
+                const int q = h + 4 * t;
+                if (q < NX) {
+                    const double bq = sbc[q];
+                    wT += bq * sP[q][cj];
+                    wA += atp(cj, q) * bq;
+                }
+            }
+            wT = cross_rows_sum(wT);
+            wA = cross_rows_sum(wA);
+            bp = wave_sum_m(isX ? sbc[vx] * sp[vx] : 0.0);
+        }
+        // ---- 3. B^T P in the U-map
+        double btp[2];
+        UNR for (int r = 0; r < 2; r++) {
+            const int i = ui[r];
+            if (TM && i == NU - 1) btp[r] = wT;
+            else btp[r] = (ND == 1) ? dt * sP[i][cj] : hdt2 * sP[i][cj] + dt * sP[DOF + i][cj];
+            if (uv[r] && colS) sBtP[i][c16] = btp[r];
+        }
+        LDS_ORDER();
+        // ---- 4. Qux~ = [B^T P A | Qu] (U-map), Qxu (U-map transposed: state c16, control h + 4r), Quu, [Qxx | Qx] (P-map)
+        double qux[2], qxu[2];
+        UNR for (int r = 0; r < 2; r++) {
+            const int i = ui[r];
+            double v = 0, w = 0;
+            if (colS) {
+                v = is_vrow(cj) ? sBtP[i][cj - DOF] * dt + btp[r] : btp[r];
+                if (TM && i == NU - 1) w = wA;
+                else w = (ND == 1) ? atp(cj, i) * dt : atp(cj, i) * hdt2 + atp(cj, DOF + i) * dt;
+            } else if (colA) {  // Qu_i = R_i u_i + (B^T p)_i
+                const double btpp = (TM && i == NU - 1) ? bp : ((ND == 1) ? dt * sp[i] : hdt2 * sp[i] + dt * sp[DOF + i]);
+                v = d.R_diag[i] * su[i] + btpp;
+            }
+            qux[r] = uv[r] ? v : 0.0;
+            qxu[r] = (uv[r] && colS) ? w : 0.0;
+        }
+        double quu;
+        {
+            double tot = 0;
+            if (TM) {  // column NU-1: sum_q BtP[qi][q] bc_q; the 8 lanes of a row add two terms each (q = qj, qj + 8), DPP butterfly
+                double part = sBtP[qi][qj] * sbc[qj];
+                if (qj + 8 < NX) part += sBtP[qi][qj + 8] * sbc[qj + 8];
+                tot = oct_sum_m(qv ? part : 0.0);
+            }
+            if (TM && qj == NU - 1) quu = tot;
+            else quu = (ND == 1) ? sBtP[qi][qj] * dt : sBtP[qi][qj] * hdt2 + sBtP[qi][DOF + qj] * dt;
+            if (qi == qj) quu = d.R_diag[qi] + quu;
+        }
+        double qxx[4];
+        UNR for (int r = 0; r < 4; r++) {
+            const int i = pi[r];
+            double v = 0;
+            if (colS) {
+                const double t0 = atp(i, cj);
+                v = is_vrow(cj) ? atp(i, cj - DOF) * dt + t0 : t0;
+            } else if (colA) {  // Qx_i = l_x_i + (A^T p)_i
+                v = is_vrow(i) ? dt * sp[i - DOF] + sp[i] : sp[i];
+            }
+            qxx[r] = pv[r] ? lq[r] + v : 0.0;
+        }
+        if (AL) {
+            const int ns = NX + NU;
+            for (int rr = 0; rr < m; rr++) {  // uniform; g = A [x;u] - b, w = lambda + I g
+                const double* Ar = a.conA + ((size_t)(a.per_step ? k : 0) * m + rr) * ns;
+                const double part = (isX ? Ar[vx] * xv : 0.0) + (isU ? Ar[NX + vu] * uv_ : 0.0);
+                const double g = wave_sum_m(part) - a.conb[(size_t)(a.per_step ? k : 0) * m + rr];
+                const double Ik = sIs[rr], wv = slam[rr] + Ik * g;
+                const double axc = Ar[cj];
+                UNR for (int r = 0; r < 2; r++) {
+                    const double au = Ar[NX + ui[r]];
+                    if (uv[r] && colS) { qux[r] += au * Ik * axc; qxu[r] += axc * Ik * au; }
+                    if (uv[r] && colA) qux[r] += au * wv;
+                }
+                quu += Ar[NX + qi] * Ik * Ar[NX + qj];
+                UNR for (int r = 0; r < 4; r++) {
+                    if (pv[r] && colS) qxx[r] += Ar[pi[r]] * Ik * axc;
+                    if (pv[r] && colA) qxx[r] += Ar[pi[r]] * wv;
+                }
+            }
+        }
+        if (qv) { sQuu[qi][qj] = quu; sS[qi][qj] = quu + ((qi == qj) ? reg : 0.0); }
+        LDS_ORDER();
+        // ---- 5. symmetric sweeps on Quu + reg I: afterwards sS = -(Quu + reg I)^-1 = Quu_inv of the reference
+        {
+            double sv = sS[qi][qj];
+            UNR for (int c = 0; c < NU; c++) {
+                const double aic = sS[qi][c], acj = sS[c][qj], acc = sS[c][c];
+                LDS_ORDER();
+                const double r = rcp_nr_m(acc);
+                const double tt = aic * r;
+                double val = fma(-tt, acj, sv);
+                if (qj == c) val = tt;
+                if (qi == c) val = acj * r;
+                if (qi == c && qj == c) val = -r;
+                sv = val;
+                if (qv) sS[qi][qj] = val;
+                LDS_ORDER();
+            }
+        }
+        // ---- 6. K~ = Quu_inv Qux~ ; T1~ = Quu K~ + Qux~ ; P~' = [Qxx | Qx] + K~^T T1~ + Qxu K~   (f64 matrix cores)
+        const bool rowU = c16 < NU;
+        const int cu = rowU ? c16 : 0;
+        const double sa0 = rowU ? sS[cu][h] : 0.0, sa1 = rowU ? sS[cu][4 + h] : 0.0;       // A operand: Quu_inv[c16][4c + h]
+        const double qa0 = rowU ? sQuu[cu][h] : 0.0, qa1 = rowU ? sQuu[cu][4 + h] : 0.0;   // A operand: Quu[c16][4c + h]
+        d4_t Kt = {0, 0, 0, 0};
+        Kt = __builtin_amdgcn_mfma_f64_16x16x4f64(sa0, qux[0], Kt, 0, 0, 0);
+        Kt = __builtin_amdgcn_mfma_f64_16x16x4f64(sa1, qux[1], Kt, 0, 0, 0);
+        UNR for (int r = 0; r < 2; r++)
+            if (uv[r] && c16 <= NX) Kout[ui[r] * ROWP + c16] = Kt[r];  // gain record row {K[i][0..NX-1], d[i]}
+        Kout -= Kstep;
+        d4_t T1 = {qux[0], qux[1], 0, 0};
+        T1 = __builtin_amdgcn_mfma_f64_16x16x4f64(qa0, Kt[0], T1, 0, 0, 0);
+        T1 = __builtin_amdgcn_mfma_f64_16x16x4f64(qa1, Kt[1], T1, 0, 0, 0);
+        d4_t Pn = {qxx[0], qxx[1], qxx[2], qxx[3]};
+        Pn = __builtin_amdgcn_mfma_f64_16x16x4f64(Kt[0], T1[0], Pn, 0, 0, 0);
+        Pn = __builtin_amdgcn_mfma_f64_16x16x4f64(Kt[1], T1[1], Pn, 0, 0, 0);
+        Pn = __builtin_amdgcn_mfma_f64_16x16x4f64(qxu[0], Kt[0], Pn, 0, 0, 0);
+        Pn = __builtin_amdgcn_mfma_f64_16x16x4f64(qxu[1], Kt[1], Pn, 0, 0, 0);
+        LDS_ORDER();
+        UNR for (int r = 0; r < 4; r++) {
+            if (pv[r] && colS) sP[pi[r]][c16] = Pn[r];
+            if (pv[r] && colA) sp[pi[r]] = Pn[r];
+        }
+        LDS_ORDER();
+      }
+    }
+}
+
+bool backward_mfma_supported(int kind, int nd, bool al, int m) {
+    static const bool off = std::getenv("ILQR_BWD") && (!std::strcmp(std::getenv("ILQR_BWD"), "v1") || !std::strcmp(std::getenv("ILQR_BWD"), "gen"));
+    (void)kind; (void)nd;
+    return !off && (!al || m <= 16);
+}
+
+template <class S>
+static void launch_mfma_sys(bool al, const Bufs& a, int B, hipStream_t st) {
+    const dim3 grid(grid_x8(B)), block(64);
+    if (al) hipLaunchKernelGGL((k_backward_mfma<S, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((k_backward_mfma<S, false>), grid, block, 0, st, a);
+}
+
+void launch_backward_mfma(int kind, int nd, bool al, const Bufs& a, int B, hipStream_t st) {
+    if (kind == 0 && nd == 1) launch_mfma_sys<Sys<0, 1>>(al, a, B, st);
+    else if (kind == 0 && nd == 2) launch_mfma_sys<Sys<0, 2>>(al, a, B, st);
+    else if (kind == 1 && nd == 1) launch_mfma_sys<Sys<1, 1>>(al, a, B, st);
+    else launch_mfma_sys<Sys<1, 2>>(al, a, B, st);
+}
+
+}  // namespace ilqr
