@@ -67,6 +67,7 @@ __global__ __launch_bounds__(64) void k_backward_mfma(Bufs a) {
     static_assert(NX <= 15 && NU <= 8, "one affine column next to the state, two k-steps of 4");
     __shared__ __attribute__((aligned(16))) double sP[16][PS], sBtP[8][PS], sS[8][TS], sQuu[8][TS];
     __shared__ __attribute__((aligned(16))) double sx[16], su[8], sbc[16], sp[16], slam[MMAX], sIs[MMAX];
+    __shared__ double sDump[64];  // target of the stores of lanes that own nothing: an unconditional ds_write is cheaper than an exec-mask branch
 
     const DevDesc& d = *a.desc;
     const int l = threadIdx.x, h = l >> 4, c16 = l & 15;
@@ -104,6 +105,16 @@ __global__ __launch_bounds__(64) void k_backward_mfma(Bufs a) {
     const bool isX = l < NX, isU = l < NU;
     const int vx = isX ? l : 0, vu = isU ? l : 0;
     auto is_vrow = [](int i) { return ND == 2 && i >= DOF && i < 2 * DOF; };
+    double* const dump = &sDump[l];
+    double* wBtP[2];
+    UNR for (int r = 0; r < 2; r++) wBtP[r] = (uv[r] && colS) ? &sBtP[ui[r]][c16] : dump;
+    double* const wS = qv ? &sS[qi][qj] : dump;
+    double* const wQuu = qv ? &sQuu[qi][qj] : dump;
+    double* wP[4];
+    UNR for (int r = 0; r < 4; r++) wP[r] = (pv[r] && colS) ? &sP[pi[r]][c16] : ((pv[r] && colA) ? &sp[pi[r]] : dump);
+    double* const wx = isX ? &sx[vx] : dump;
+    double* const wu = isU ? &su[vu] : dump;
+    double* const wbc = isX ? &sbc[vx] : dump;
 
     // limit parameters of the entries this lane needs: diagonal P-map entries (l_xx) and the affine column (l_x)
     bool dgl[4];
@@ -183,8 +194,8 @@ __global__ __launch_bounds__(64) void k_backward_mfma(Bufs a) {
         fetch(jj, k - PF);
         if (k < 0) continue;  // uniform: dummy step of the last group
         // ---- 1. x, u, (lambda, I) into LDS; time column of B
-        if (isX) sx[vx] = xv;
-        if (isU) su[vu] = uv_;
+        *wx = xv;
+        *wu = uv_;
         if (AL && l < m) { slam[l] = lamv; sIs[l] = isv; }
         LDS_ORDER();
         const double dts = TM ? su[NU - 1] : 0.0;
@@ -204,7 +215,7 @@ __global__ __launch_bounds__(64) void k_backward_mfma(Bufs a) {
             } else if (l == NX - 1) {
                 bcv = 2 * dts;
             }
-            if (isX) sbc[vx] = bcv;
+            *wbc = bcv;
         }
         double lq[4];
         stage_terms(k, lq);
@@ -232,7 +243,7 @@ __global__ __launch_bounds__(64) void k_backward_mfma(Bufs a) {
             const int i = ui[r];
             if (TM && i == NU - 1) btp[r] = wT;
             else btp[r] = (ND == 1) ? dt * sP[i][cj] : hdt2 * sP[i][cj] + dt * sP[DOF + i][cj];
-            if (uv[r] && colS) sBtP[i][c16] = btp[r];
+            *wBtP[r] = btp[r];
         }
         LDS_ORDER();
         // ---- 4. Qux~ = [B^T P A | Qu] (U-map), Qxu (U-map transposed: state c16, control h + 4r), Quu, [Qxx | Qx] (P-map)
@@ -295,7 +306,8 @@ __global__ __launch_bounds__(64) void k_backward_mfma(Bufs a) {
                 }
             }
         }
-        if (qv) { sQuu[qi][qj] = quu; sS[qi][qj] = quu + ((qi == qj) ? reg : 0.0); }
+        *wQuu = quu;
+        *wS = quu + ((qi == qj) ? reg : 0.0);
         LDS_ORDER();
         // ---- 5. symmetric sweeps on Quu + reg I: afterwards sS = -(Quu + reg I)^-1 = Quu_inv of the reference
         {
@@ -310,7 +322,7 @@ __global__ __launch_bounds__(64) void k_backward_mfma(Bufs a) {
                 if (qi == c) val = acj * r;
                 if (qi == c && qj == c) val = -r;
                 sv = val;
-                if (qv) sS[qi][qj] = val;
+                *wS = val;
                 LDS_ORDER();
             }
         }
@@ -334,10 +346,7 @@ __global__ __launch_bounds__(64) void k_backward_mfma(Bufs a) {
         Pn = __builtin_amdgcn_mfma_f64_16x16x4f64(qxu[0], Kt[0], Pn, 0, 0, 0);
         Pn = __builtin_amdgcn_mfma_f64_16x16x4f64(qxu[1], Kt[1], Pn, 0, 0, 0);
         LDS_ORDER();
-        UNR for (int r = 0; r < 4; r++) {
-            if (pv[r] && colS) sP[pi[r]][c16] = Pn[r];
-            if (pv[r] && colA) sp[pi[r]] = Pn[r];
-        }
+        UNR for (int r = 0; r < 4; r++) *wP[r] = Pn[r];
         LDS_ORDER();
       }
     }
