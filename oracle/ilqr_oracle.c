@@ -256,11 +256,76 @@ void orc_system_finalize(orc_system* s) {
 
 /* getFxJac(xk): System.cpp:163-179 + PosOrnPlannerSys.cpp:80-102 ; PosOrnTimePlannerSys.cpp:85-137.
  * fx = [p; quat (; dp; dquat) (; t)], J = Jac | blkdiag(Jac,Jac) | bordered with 1 for the time state. */
-void orc_get_fx_jac(const orc_system* s, const double* x, double* fx, double* J) {
+/* Eigen::Quaterniond::toRotationMatrix (Eigen/src/Geometry/Quaternion.h), q = (w,x,y,z), no normalisation; row-major out */
+static void eig_quat_to_mat(const double q[4], double m[9]) {
+    const double w = q[0], x = q[1], y = q[2], z = q[3];
+    const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    m[0] = 1 - (tyy + tzz); m[1] = txy - twz; m[2] = txz + twy;
+    m[3] = txy + twz; m[4] = 1 - (txx + tzz); m[5] = tyz - twx;
+    m[6] = txz - twy; m[7] = tyz + twx; m[8] = 1 - (txx + tyy);
+}
+/* Eigen::Quaterniond(Matrix3d) (quaternionbase_assign_impl<Other,3,3>): trace > 0 branch, else largest diagonal */
+static void eig_mat_to_quat(const double m[9], double q[4]) {
+    double t = m[0] + m[4] + m[8];
+    double c[3]; /* x, y, z */
+    if (t > 0) {
+        t = sqrt(t + 1.0);
+        q[0] = 0.5 * t;
+        t = 0.5 / t;
+        c[0] = (m[7] - m[5]) * t; c[1] = (m[2] - m[6]) * t; c[2] = (m[3] - m[1]) * t;
+    } else {
+        int i = 0;
+        if (m[4] > m[0]) i = 1;
+        if (m[8] > m[i * 3 + i]) i = 2;
+        int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrt(m[i * 3 + i] - m[j * 3 + j] - m[k * 3 + k] + 1.0);
+        c[i] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (m[k * 3 + j] - m[j * 3 + k]) * t;
+        c[j] = (m[j * 3 + i] + m[i * 3 + j]) * t;
+        c[k] = (m[k * 3 + i] + m[i * 3 + k]) * t;
+    }
+    q[1] = c[0]; q[2] = c[1]; q[3] = c[2];
+}
+
+/* getFxJac (PosOrnPlannerSys.cpp:80-102, PosOrnTimePlannerSys.cpp:85-112) seen through the keypoint's frame when it has one
+ * (TransformedSimulationInterface.cpp:53-103): p' = R'(p - t), R_ee' = R' R_ee -> Eigen quaternion, J' = blkdiag(R,R)' J,
+ * dx' = R' dx, w' = R' w. */
+static void fx_jac_frame(const orc_system* s, const orc_keypoint* kp, const double* x, double* fx, double* J) {
     int dof = s->dof, nd = s->nb_deriv, tm = (s->kind == ORC_SYS_POS_ORN_TIME);
     double p[3], quat[4], Jac[6 * ORC_MAX_DOF], dx[3], w[3], dq0[ORC_MAX_DOF] = {0};
     const double* dq = (nd == 2) ? x + dof : dq0;
     orc_fk(&s->chain, x, dq, p, quat, Jac, dx, w);
+    if (kp && kp->has_frame) {
+        const double* R = kp->fR;
+        double pp[3], ree[9], mm_[9], dxp[3], wp[3], Jn[6 * ORC_MAX_DOF];
+        for (int i = 0; i < 3; i++) {
+            pp[i] = 0; dxp[i] = 0; wp[i] = 0;
+            for (int j = 0; j < 3; j++) {  /* R^T v */
+                pp[i] += R[j * 3 + i] * (p[j] - kp->fp[j]);
+                dxp[i] += R[j * 3 + i] * dx[j];
+                wp[i] += R[j * 3 + i] * w[j];
+            }
+        }
+        eig_quat_to_mat(quat, ree);
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                double a = 0;
+                for (int l = 0; l < 3; l++) a += R[l * 3 + i] * ree[l * 3 + j];
+                mm_[i * 3 + j] = a;
+            }
+        eig_mat_to_quat(mm_, quat);
+        for (int blk = 0; blk < 2; blk++)
+            for (int i = 0; i < 3; i++)
+                for (int c = 0; c < dof; c++) {
+                    double a = 0;
+                    for (int l = 0; l < 3; l++) a += R[l * 3 + i] * Jac[(3 * blk + l) * dof + c];
+                    Jn[(3 * blk + i) * dof + c] = a;
+                }
+        memcpy(Jac, Jn, sizeof(double) * 6 * dof);
+        memcpy(p, pp, sizeof(pp)); memcpy(dx, dxp, sizeof(dxp)); memcpy(w, wp, sizeof(wp));
+    }
     if (fx) {
         memset(fx, 0, sizeof(double) * s->n_f);
         memcpy(fx, p, 3 * sizeof(double));
@@ -285,6 +350,7 @@ void orc_get_fx_jac(const orc_system* s, const double* x, double* fx, double* J)
         if (tm) J[(s->n_Q - 1) * nx + nx - 1] = 1;
     }
 }
+void orc_get_fx_jac(const orc_system* s, const double* x, double* fx, double* J) { fx_jac_frame(s, NULL, x, fx, J); }
 
 /* PosOrnKeypoint::diff (PosOrnKeypoint.cpp:24-45), SpacetimeKeypoint::diff (SpacetimeKeypoint.cpp:19-25) */
 void orc_kp_diff(const orc_system* s, const orc_keypoint* kp, const double* fx, double* e) {
@@ -347,19 +413,20 @@ double orc_cost(const orc_system* s, const double* x, const double* u, int k) {
     const orc_keypoint* kp = find_kp(s, k);
     if (kp) {
         double fx[ORC_MAX_NF], e[ORC_MAX_NQ], Qe[ORC_MAX_NQ];
-        orc_get_fx_jac(s, x, fx, NULL);
+        fx_jac_frame(s, kp, x, fx, NULL);
         orc_kp_diff(s, kp, fx, e);
         int nq = s->n_Q;
         for (int i = 0; i < nq; i++) Qe[i] = dot(kp->Q + i * nq, e, nq);
         double ru = 0;
-        for (int i = 0; i < s->n_u; i++) ru += u[i] * s->R_diag[i] * u[i];
+        const double* Rk = kp->has_Ru ? kp->Ru : s->R_diag;
+        for (int i = 0; i < s->n_u; i++) ru += u[i] * Rk[i] * u[i];
         c += dot(e, Qe, nq) + ru;
     }
     if (s->limits_set) {
         double Ld[ORC_MAX_NX], q[ORC_MAX_NX], a = 0;
         limits(s, x, Ld, q);
         for (int i = 0; i < s->n_x; i++) a += q[i] * Ld[i] * q[i];
-        c += a;
+        c += a * (s->lim_mult > 1 ? s->lim_mult : 1);
     }
     return c;
 }
@@ -371,7 +438,7 @@ void orc_cost_x(const orc_system* s, const double* x, int k, double* lx) {
     const orc_keypoint* kp = find_kp(s, k);
     if (kp) {
         double fx[ORC_MAX_NF], J[ORC_MAX_NQ * ORC_MAX_NX], e[ORC_MAX_NQ], Qe[ORC_MAX_NQ];
-        orc_get_fx_jac(s, x, fx, J);
+        fx_jac_frame(s, kp, x, fx, J);
         orc_kp_diff(s, kp, fx, e);
         for (int i = 0; i < nq; i++) Qe[i] = dot(kp->Q + i * nq, e, nq);
         for (int c = 0; c < nx; c++) {
@@ -383,7 +450,7 @@ void orc_cost_x(const orc_system* s, const double* x, int k, double* lx) {
     if (s->limits_set) {
         double Ld[ORC_MAX_NX], q[ORC_MAX_NX];
         limits(s, x, Ld, q);
-        for (int i = 0; i < nx; i++) lx[i] += -Ld[i] * q[i];
+        for (int i = 0; i < nx; i++) lx[i] += -Ld[i] * q[i] * (s->lim_mult > 1 ? s->lim_mult : 1);
     }
 }
 
@@ -394,7 +461,7 @@ void orc_cost_xx(const orc_system* s, const double* x, int k, double* lxx) {
     const orc_keypoint* kp = find_kp(s, k);
     if (kp) {
         double J[ORC_MAX_NQ * ORC_MAX_NX], JtQ[ORC_MAX_NX * ORC_MAX_NQ], JtQJ[ORC_MAX_NX * ORC_MAX_NX];
-        orc_get_fx_jac(s, x, NULL, J);
+        fx_jac_frame(s, kp, x, NULL, J);
         mtm(JtQ, J, kp->Q, nq, nx, nq);
         mm(JtQJ, JtQ, J, nx, nq, nx);
         for (int i = 0; i < nx * nx; i++) lxx[i] += JtQJ[i];
@@ -402,7 +469,7 @@ void orc_cost_xx(const orc_system* s, const double* x, int k, double* lxx) {
     if (s->limits_set) {
         double Ld[ORC_MAX_NX], q[ORC_MAX_NX];
         limits(s, x, Ld, q);
-        for (int i = 0; i < nx; i++) lxx[i * nx + i] += Ld[i] * Ld[i];
+        for (int i = 0; i < nx; i++) lxx[i * nx + i] += Ld[i] * Ld[i] * (s->lim_mult > 1 ? s->lim_mult : 1);
     }
 }
 
@@ -690,7 +757,7 @@ static void fp_batch_run(const orc_system* s, const double* u, fp_batch* f) {
     init_state(s, x);
     memset(f->qL, 0, sizeof(double) * T * nx);
     memset(f->L, 0, sizeof(double) * T * nx);
-    orc_get_fx_jac(s, x, f->fX, f->J);
+    fx_jac_frame(s, find_kp(s, 0), x, f->fX, f->J);
     memset(f->A, 0, sizeof(double) * nx * nx);
     for (int i = 0; i < nx; i++) f->A[i * nx + i] = 1;
     memset(f->B, 0, sizeof(double) * nx * nu);
@@ -698,6 +765,10 @@ static void fp_batch_run(const orc_system* s, const double* u, fp_batch* f) {
         orc_step(s, x, u + (size_t)i * nu, xn, f->fX + (size_t)(i + 1) * nf, f->A + (size_t)(i + 1) * nx * nx,
                  f->B + (size_t)(i + 1) * nx * nu, f->J + (size_t)(i + 1) * nq * nx);
         limits(s, x, f->L + (size_t)(i + 1) * nx, f->qL + (size_t)(i + 1) * nx);
+        {   /* a keypoint whose system works in an object frame (TransformedSimulationInterface): f(x) and J in that frame */
+            const orc_keypoint* kf = find_kp(s, i + 1);
+            if (kf && kf->has_frame) fx_jac_frame(s, kf, xn, f->fX + (size_t)(i + 1) * nf, f->J + (size_t)(i + 1) * nq * nx);
+        }
         memcpy(x, xn, sizeof(x));
     }
 }

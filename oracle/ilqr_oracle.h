@@ -54,6 +54,14 @@ typedef struct {
     double Q[ORC_MAX_NQ * ORC_MAX_NQ]; /* row-major n_Q x n_Q precision */
     int dist;                   /* 1 = PosOrnKeypointDistFunct (PosOrnKeypointDistFunct.h:15-44) */
     double pos_radius, orn_thresh[3];
+    /* the keypoint's sub-system sees the robot through a TransformedSimulationInterface (sim/TransformedSimulationInterface.cpp:
+     * 53-103): pose and Jacobian expressed in the frame T = [fR | fp] (fR row-major) */
+    int has_frame;
+    double fR[9], fp[3];
+    /* control penalty of the OWNING sub-system of a SequentialSystem (its cost adds u'R_sub u at its keypoint steps,
+     * SequentialSystem.cpp:144-150 -> System.cpp:221); 0 = the system's R_diag */
+    int has_Ru;
+    double Ru[ORC_MAX_NU];
 } orc_keypoint;
 
 typedef struct {
@@ -64,6 +72,7 @@ typedef struct {
     double dt;      /* PosOrn only */
     double R_diag[ORC_MAX_NU];
     int limits_set;
+    int lim_mult;                         /* SequentialSystem: every sub-system adds the limit terms once (SequentialSystem.cpp:144-168); 0 = 1 */
     double penalty;                       /* System.cpp:40,72 */
     double state_max[ORC_MAX_NX], state_min[ORC_MAX_NX];
     int limit_weight[ORC_MAX_NX];

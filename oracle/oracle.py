@@ -47,6 +47,11 @@ class Keypoint(C.Structure):
         ("dist", C.c_int),
         ("pos_radius", C.c_double),
         ("orn_thresh", C.c_double * 3),
+        ("has_frame", C.c_int),
+        ("fR", C.c_double * 9),
+        ("fp", C.c_double * 3),
+        ("has_Ru", C.c_int),
+        ("Ru", C.c_double * MAX_NU),
     ]
 
 
@@ -59,6 +64,7 @@ class System(C.Structure):
         ("dt", C.c_double),
         ("R_diag", C.c_double * MAX_NU),
         ("limits_set", C.c_int),
+        ("lim_mult", C.c_int),
         ("penalty", C.c_double),
         ("state_max", C.c_double * MAX_NX),
         ("state_min", C.c_double * MAX_NX),
@@ -223,12 +229,13 @@ def make_chain(segs) -> Chain:
 # ----------------------------------------------------------------------------- problem construction
 
 
-def make_system(segs, kind, nb_deriv, T, dt, R_diag, keypoints, q0, dq0=None, qMax=None, qMin=None, dqMax=None, dqMin=None) -> System:
+def make_system(segs, kind, nb_deriv, T, dt, R_diag, keypoints, q0, dq0=None, qMax=None, qMin=None, dqMax=None, dqMin=None, lim_mult=1) -> System:
     """Mirror of the System constructors (reference src/system/System.cpp:19-75) + localInit.
     keypoints: list of dict(timestep,pos,orn,Q[,dpos,dorn][,ctime]); sorted by timestep here (System.cpp:82)."""
     s = System()
     s.chain = make_chain(segs)
     s.kind, s.nb_deriv, s.T, s.dt = kind, nb_deriv, T, float(dt if dt is not None else 0.0)
+    s.lim_mult = int(lim_mult)  # SequentialSystem: number of sub-systems (each adds the limit terms)
     L = lib()
     L.orc_system_finalize(C.byref(s))
     dof = s.dof
@@ -273,6 +280,17 @@ def make_system(segs, kind, nb_deriv, T, dt, R_diag, keypoints, q0, dq0=None, qM
         for a in range(nq):
             for b in range(nq):
                 kp.Q[a * nq + b] = Q[a, b]
+        if k.get("frame") is not None:  # 4x4 pose of the frame the keypoint's sub-system works in (TransformedSimulationInterface)
+            Tm = _arr(k["frame"]).reshape(4, 4)
+            kp.has_frame = 1
+            for a in range(3):
+                kp.fp[a] = Tm[a, 3]
+                for b in range(3):
+                    kp.fR[a * 3 + b] = Tm[a, b]
+        if k.get("Ru") is not None:  # control penalty of the owning sub-system (SequentialSystem)
+            kp.has_Ru = 1
+            for a, v in enumerate(k["Ru"]):
+                kp.Ru[a] = float(v)
         if k.get("dist") is not None:  # PosOrnKeypointDistFunct: dict(pos_radius, orn_thresh[3])
             kp.dist = 1
             kp.pos_radius = float(k["dist"]["pos_radius"])

@@ -103,6 +103,46 @@ cases["POS_ORN_TIME_SYS_2ND"] = dict(
             dict(solver="ILQRRecursive", nb_iter=20, line_search=True, early_stop=True, **t[1]),
             dict(solver="BatchILQR", nb_iter=20, early_stop=True, **t[2])])
 
+# ---- object-frame tutorials: TransformedSimulationInterface / SequentialSystem (literals of cells 8-16 of the two notebooks)
+def frame_of(quat_wxyz, pos):
+    """4x4 pose as the notebooks build it: scipy Rotation.from_quat(xyzw).as_matrix() (normalised quaternion) + position."""
+    w, x, y, z = quat_wxyz
+    n = (w * w + x * x + y * y + z * z) ** 0.5
+    w, x, y, z = w / n, x / n, y / n, z / n
+    R = [[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]]
+    return [R[0] + [pos[0]], R[1] + [pos[1]], R[2] + [pos[2]], [0, 0, 0, 1]]
+
+
+OBJ1 = frame_of([0.63758403393523, 0.2994657314658187, 0.6042309402208079, -0.37244039285286973], [0.62, 0.05, 0.34])
+OBJ2 = frame_of([-0.03647984, 0.94060485, 0.33742794, 0.00860923], [0.32, 0.05, 0.54])
+
+
+def frame_problem(T, dt, kps, n_sub):
+    dof = 7
+    return dict(kind="POS_ORN", nb_deriv=1, T=T, dt=dt, q0=Q0_TUT, dq0=[0] * dof, R_diag=[1e-5] * dof,
+                qMax=[PI10] * dof, qMin=[-PI10] * dof, dqMax=[10.0] * dof, dqMin=[-10.0] * dof,
+                keypoints=kps, u0_step=[0.0] * dof, base="panda_link0", tip="panda_tip", lim_mult=n_sub)
+
+
+t = traces_of("POS_ORN_SYS_OBJ_FRAME.ipynb")
+cases["POS_ORN_SYS_OBJ_FRAME"] = dict(  # one PosOrnPlannerSys on TransformedSimulationInterface(rbt, obj1_frame)
+    problem=frame_problem(400, 0.01, [
+        dict(timestep=199, pos=[-0.30, 0.10, -0.15], orn=[1, 0, 0, 0], Qdiag=P, frame=OBJ1),
+        dict(timestep=399, pos=[0, 0, -0.15], orn=[1, 0, 0, 0], Qdiag=P, frame=OBJ1)], 1),
+    solves=[dict(solver="BatchILQRCP", psi=dict(kind="unitstep", K=2), nb_iter=25, early_stop=True, **t[0]),
+            dict(solver="ILQRRecursive", nb_iter=10, line_search=True, early_stop=True, **t[1])])
+
+t = traces_of("POS_ORN_MULTI_SYS.ipynb")
+cases["POS_ORN_MULTI_SYS"] = dict(  # SequentialSystem(rbt, [sys1 in obj1_frame (keypoint at T/2), sys2 in obj2_frame (keypoint at T-1)])
+    problem=frame_problem(600, 0.01, [
+        dict(timestep=300, pos=[0, 0, -0.15], orn=[1, 0, 0, 0], Qdiag=[1, 1, 1, 0, 0, 0], frame=OBJ1, Ru=[1e-5] * 7),
+        dict(timestep=599, pos=[0.1, 0.1, -0.1], orn=[1, 0, 0, 0], Qdiag=[1, 1, 1, 0, 0, 0], frame=OBJ2, Ru=[1e-5] * 7)], 2),
+    # the BatchILQRCP solve of this notebook (stacked residuals of both sub-systems) is not restated: its trace is kept for later
+    solves=[dict(solver="BatchILQRCP_sequential", psi=dict(kind="unitstep", K=2), nb_iter=25, early_stop=True, **t[0]),
+            dict(solver="ILQRRecursive", nb_iter=10, line_search=True, early_stop=True, **t[1])])
+
 # FK literals stored in the notebooks (POS_ORN_MULTI_SYS.ipynb cell 8: pose of the tutorial q0, incl. negative w)
 nb = json.load(open(os.path.join(REF, "POS_ORN_MULTI_SYS.ipynb")))
 src = "".join("".join(c["source"]) for c in nb["cells"] if c["cell_type"] == "code")

@@ -37,7 +37,7 @@ def oracle_system(prob, segs=None):
         d["Q"] = np.diag(k["Qdiag"]) if "Qdiag" in k else np.asarray(k["Q"])
         kps.append(d)
     return orc.make_system(segs, kind, prob["nb_deriv"], prob["T"], prob["dt"], prob["R_diag"], kps, prob["q0"], prob["dq0"],
-                           prob.get("qMax"), prob.get("qMin"), prob.get("dqMax"), prob.get("dqMin"))
+                           prob.get("qMax"), prob.get("qMin"), prob.get("dqMax"), prob.get("dqMin"), prob.get("lim_mult", 1))
 
 
 def u0_of(prob):
