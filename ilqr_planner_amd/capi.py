@@ -59,6 +59,12 @@ class ProblemDesc(C.Structure):
         ("kp_dist", C.c_int * MAX_KP),
         ("kp_pos_radius", C.c_double * MAX_KP),
         ("kp_orn_thresh", (C.c_double * 3) * MAX_KP),
+        ("kp_has_frame", C.c_int * MAX_KP),
+        ("kp_frame_R", (C.c_double * 9) * MAX_KP),
+        ("kp_frame_p", (C.c_double * 3) * MAX_KP),
+        ("kp_has_Ru", C.c_int * MAX_KP),
+        ("kp_Ru", (C.c_double * MAX_NU) * MAX_KP),
+        ("limit_multiplicity", C.c_int),
         ("reg", C.c_double),
         ("alpha_floor", C.c_double),
         ("stop_tol", C.c_double),
@@ -152,7 +158,8 @@ def chain_from_urdf(urdf_text: str, base: str, tip: str, tool_rpy=None, tool_xyz
                 lower=lo[: d.dof].copy(), upper=up[: d.dof].copy())
 
 
-def make_desc(*, kind, nb_deriv, horizon, dt, R_diag, chain, kp_timesteps, kp_Q, limits=None, kp_dist=None) -> ProblemDesc:
+def make_desc(*, kind, nb_deriv, horizon, dt, R_diag, chain, kp_timesteps, kp_Q, limits=None, kp_dist=None, kp_frames=None, kp_Ru=None,
+              limit_multiplicity=1) -> ProblemDesc:
     """chain: dict(seg_joint, seg_xyz, seg_R, seg_axis, dof); limits: dict(state_max, state_min, limit_weight, penalty) or None."""
     L = load()
     d = ProblemDesc()
@@ -188,6 +195,20 @@ def make_desc(*, kind, nb_deriv, horizon, dt, R_diag, chain, kp_timesteps, kp_Q,
         for a in range(nq):
             for b in range(nq):
                 d.kp_Q[k][a * nq + b] = Q[a, b]
+    d.limit_multiplicity = int(limit_multiplicity)  # SequentialSystem: number of sub-systems
+    for k, fr in enumerate(kp_frames or []):  # 4x4 pose of the object frame of keypoint k's sub-system (TransformedSimulationInterface) or None
+        if fr is not None:
+            Tm = _f64(fr, (4, 4))
+            d.kp_has_frame[k] = 1
+            for a in range(3):
+                d.kp_frame_p[k][a] = Tm[a, 3]
+                for b in range(3):
+                    d.kp_frame_R[k][a * 3 + b] = Tm[a, b]
+    for k, ru in enumerate(kp_Ru or []):  # control penalty of keypoint k's own sub-system (SequentialSystem) or None
+        if ru is not None:
+            d.kp_has_Ru[k] = 1
+            for a, v in enumerate(ru):
+                d.kp_Ru[k][a] = float(v)
     for k, kd in enumerate(kp_dist or []):  # PosOrnKeypointDistFunct: None or dict(pos_radius=..., orn_thresh=[3])
         if kd is not None:
             d.kp_dist[k] = 1

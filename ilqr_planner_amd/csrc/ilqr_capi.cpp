@@ -235,7 +235,12 @@ static int lower_desc(ilqr_ctx* c, const ilqr_problem_desc& d, int B, int Bp, De
     if (d.horizon < 2) return fail(c, "horizon must be >= 2");
     h.kind = d.kind; h.nd = d.nb_deriv; h.T = d.horizon; h.B = B; h.Bp = Bp; h.dt = d.dt;
     for (int i = 0; i < dm.n_u; i++) h.R_diag[i] = d.R_diag[i];
-    h.limits_set = d.limits_set; h.penalty = d.penalty;
+    {   // SequentialSystem: every sub-system adds the limit terms once -- q'Lq and L'q scale with the multiplicity, L'L too
+        const double mult = d.limit_multiplicity > 1 ? (double)d.limit_multiplicity : 1.0;
+        h.limits_set = d.limits_set;
+        h.penalty = d.penalty * mult;
+        h.pen_xx = d.penalty * d.penalty * mult;
+    }
     for (int i = 0; i < dm.n_x; i++) { h.smax[i] = d.state_max[i]; h.smin[i] = d.state_min[i]; h.lw[i] = d.limit_weight[i]; }
     if (d.n_kp < 0 || d.n_kp > ILQR_MAX_KP) return fail(c, "bad n_kp");
     h.n_kp = d.n_kp;
@@ -245,6 +250,11 @@ static int lower_desc(ilqr_ctx* c, const ilqr_problem_desc& d, int B, int Bp, De
         h.kp_t[k] = d.kp_timestep[k];
         for (int i = 0; i < dm.n_Q * dm.n_Q; i++) h.kp_Q[k][i] = d.kp_Q[k][i];
         h.kp_dist[k] = d.kp_dist[k];
+        h.kp_frame[k] = d.kp_has_frame[k];
+        for (int i = 0; i < 9; i++) h.kp_fR[k][i] = d.kp_frame_R[k][i];
+        for (int i = 0; i < 3; i++) h.kp_fp[k][i] = d.kp_frame_p[k][i];
+        h.kp_has_Ru[k] = d.kp_has_Ru[k];
+        for (int i = 0; i < dm.n_u; i++) h.kp_Ru[k][i] = d.kp_Ru[k][i];
         h.kp_pos_radius[k] = d.kp_pos_radius[k];
         for (int i = 0; i < 3; i++) h.kp_orn_thresh[k][i] = d.kp_orn_thresh[k][i];
     }

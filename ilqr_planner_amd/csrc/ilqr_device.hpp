@@ -45,6 +45,11 @@ struct DevDesc {
     double kp_Q[MAX_KP][MAX_NQ * MAX_NQ];  // leading dimension n_Q
     int kp_dist[MAX_KP];               // PosOrnKeypointDistFunct dead zones (0 = plain keypoint)
     double kp_pos_radius[MAX_KP], kp_orn_thresh[MAX_KP][3];
+    int kp_frame[MAX_KP];              // keypoint seen through a TransformedSimulationInterface: frame [R | p]
+    double kp_fR[MAX_KP][9], kp_fp[MAX_KP][3];
+    int kp_has_Ru[MAX_KP];             // control penalty of the keypoint's own sub-system (SequentialSystem)
+    double kp_Ru[MAX_KP][MAX_NU];
+    double pen_xx;                     // penalty^2 x limit multiplicity (l_xx of a violated limit); `penalty` holds penalty x multiplicity
 };
 
 template <int KIND_, int ND_>
@@ -195,13 +200,82 @@ ILQR_DEV void fk(const DevChain& c, const double* q, double p[3], double quat[4]
     }
 }
 
+// Eigen::Quaterniond::toRotationMatrix / Quaterniond(Matrix3d) as TransformedSimulationInterface::getEEOrnQuat uses them
+// (q = (w,x,y,z), row-major matrix; trace > 0 branch, else the largest diagonal entry)
+ILQR_DEV void eig_quat_to_mat(const double* q, double* m) {
+    const double w = q[0], x = q[1], y = q[2], z = q[3];
+    const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    m[0] = 1 - (tyy + tzz); m[1] = txy - twz; m[2] = txz + twy;
+    m[3] = txy + twz; m[4] = 1 - (txx + tzz); m[5] = tyz - twx;
+    m[6] = txz - twy; m[7] = tyz + twx; m[8] = 1 - (txx + tyy);
+}
+ILQR_DEV void eig_mat_to_quat(const double* m, double* q) {
+    double t = m[0] + m[4] + m[8];
+    if (t > 0) {
+        t = sqrt(t + 1.0);
+        q[0] = 0.5 * t;
+        t = 0.5 / t;
+        q[1] = (m[7] - m[5]) * t; q[2] = (m[2] - m[6]) * t; q[3] = (m[3] - m[1]) * t;
+    } else if (m[0] >= m[4] && m[0] >= m[8]) {  // i = 0 (ties resolve as Eigen's strict '>' comparisons do)
+        t = sqrt(m[0] - m[4] - m[8] + 1.0);
+        q[1] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (m[7] - m[5]) * t; q[2] = (m[3] + m[1]) * t; q[3] = (m[6] + m[2]) * t;
+    } else if (m[4] > m[0] && m[4] >= m[8]) {   // i = 1
+        t = sqrt(m[4] - m[8] - m[0] + 1.0);
+        q[2] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (m[2] - m[6]) * t; q[3] = (m[7] + m[5]) * t; q[1] = (m[1] + m[3]) * t;
+    } else {                                    // i = 2
+        t = sqrt(m[8] - m[0] - m[4] + 1.0);
+        q[3] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (m[3] - m[1]) * t; q[1] = (m[2] + m[6]) * t; q[2] = (m[5] + m[7]) * t;
+    }
+}
+
 // f(x) of getFxJac: [p; quat (; dp; dquat) (; t)]  and the 6x7 Jacobian block (the full J is blkdiag(J,J) bordered by 1)
 template <class S, bool WANT_J>
-ILQR_DEV void fx_of(const DevDesc& d, const double* x, double* fxv, double (*J)[DOF]) {
+ILQR_DEV void fx_of(const DevDesc& d, const double* x, double* fxv, double (*J)[DOF], int kpi = -1) {
     double Jl[6][DOF];
     double (*Jp)[DOF] = (WANT_J || S::ND == 2) ? (WANT_J ? J : Jl) : nullptr;
     if (WANT_J || S::ND == 2) fk<true>(d.chain, x, fxv, fxv + 3, Jp);
     else fk<false>(d.chain, x, fxv, fxv + 3, nullptr);
+    if (kpi >= 0 && d.kp_frame[kpi]) {  // TransformedSimulationInterface.cpp:53-103
+        const double* R = d.kp_fR[kpi];
+        double pp[3], ree[9], mm[9];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            double a = 0;
+#pragma unroll
+            for (int j = 0; j < 3; j++) a += R[j * 3 + i] * (fxv[j] - d.kp_fp[kpi][j]);
+            pp[i] = a;
+        }
+        eig_quat_to_mat(fxv + 3, ree);
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                double a = 0;
+#pragma unroll
+                for (int l = 0; l < 3; l++) a += R[l * 3 + i] * ree[l * 3 + j];
+                mm[i * 3 + j] = a;
+            }
+        eig_mat_to_quat(mm, fxv + 3);
+#pragma unroll
+        for (int i = 0; i < 3; i++) fxv[i] = pp[i];
+        if (Jp) {
+#pragma unroll
+            for (int blk = 0; blk < 2; blk++)
+#pragma unroll
+                for (int c = 0; c < DOF; c++) {
+                    const double v0 = Jp[3 * blk][c], v1 = Jp[3 * blk + 1][c], v2 = Jp[3 * blk + 2][c];
+#pragma unroll
+                    for (int i = 0; i < 3; i++) Jp[3 * blk + i][c] = R[i] * v0 + R[3 + i] * v1 + R[6 + i] * v2;
+                }
+        }
+    }
     if (S::ND == 2) {
         double w[3] = {0, 0, 0};
 #pragma unroll
@@ -298,7 +372,7 @@ ILQR_DEV double limit_cost(const DevDesc& d, const double* x) {
 template <class S>
 ILQR_DEV double kp_cost(const DevDesc& d, int kpi, const double* tg, const double* x, const double* u) {
     double fxv[S::NF], e[S::NQ];
-    fx_of<S, false>(d, x, fxv, nullptr);
+    fx_of<S, false>(d, x, fxv, nullptr, kpi);
     kp_diff<S>(tg, fxv, e);
     kp_deadzone(d, kpi, e);
     const double* Q = d.kp_Q[kpi];
@@ -313,7 +387,7 @@ ILQR_DEV double kp_cost(const DevDesc& d, int kpi, const double* tg, const doubl
     double ru = 0;
     if (u) {
 #pragma unroll
-        for (int i = 0; i < S::NU; i++) ru += u[i] * d.R_diag[i] * u[i];
+        for (int i = 0; i < S::NU; i++) ru += u[i] * (d.kp_has_Ru[kpi] ? d.kp_Ru[kpi][i] : d.R_diag[i]) * u[i];
     }
     return c + ru;
 }

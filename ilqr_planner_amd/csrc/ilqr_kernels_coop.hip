@@ -68,7 +68,7 @@ __global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a) {
     const double dt = d.dt, idt = 1.0 / dt, idt2 = idt * idt, reg = d.reg, dt2 = dt * dt;
     const double Rv = d.R_diag[v], Dv = Rv + reg;
     const int lim_on = d.limits_set;
-    const double pen = d.penalty;
+    const double pen = d.penalty, pen_xx = d.pen_xx;
     const double smax_v = d.smax[v], smin_v = d.smin[v];
     const int lw_v = d.lw[v];
 
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a) {
         } else if (lim_on) {
             UNR for (int e = 0; e < EPL; e++) {
                 const double xi = AT(X, (T - 1) * N + ei[e], bb);
-                if (dg[e] && lw_i[e] != 0 && (xi > smax_i[e] || xi < smin_i[e])) P[e] = pen * pen;
+                if (dg[e] && lw_i[e] != 0 && (xi > smax_i[e] || xi < smin_i[e])) P[e] = pen_xx;
             }
             if (lw_v != 0) {
                 if (xv > smax_v) p = -pen * (smax_v - xv);
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a) {
         } else if (lim_on) {
             UNR for (int e = 0; e < EPL; e++) {
                 const double xi = sV[g][0][ei[e]];
-                if (dg[e] && lw_i[e] != 0 && (xi > smax_i[e] || xi < smin_i[e])) lxx[e] = pen * pen;
+                if (dg[e] && lw_i[e] != 0 && (xi > smax_i[e] || xi < smin_i[e])) lxx[e] = pen_xx;
             }
             if (lw_v != 0) {
                 if (xv > smax_v) lx = -pen * (smax_v - xv);

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(64) void k_backward_gen(Bufs a) {
     const int cur = a.cur[b];
     const double* X = a.X[cur];
     const double* U = a.U[cur];
-    const double reg = d.reg, pen = d.penalty;
+    const double reg = d.reg, pen = d.penalty, pen_xx = d.pen_xx;
     const int lim_on = d.limits_set;
     const int m = AL ? a.m : 0;
 
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(64) void k_backward_gen(Bufs a) {
             UNR for (int q = 0; q < BLK * BLK; q++)
                 if (dgl[q]) {
                     const double xi = sx[dgi[q]];
-                    if (xi > dmx[q] || xi < dmn[q]) lxxb[q] = pen * pen;
+                    if (xi > dmx[q] || xi < dmn[q]) lxxb[q] = pen_xx;
                 }
             if (isX && lw_v != 0) {
                 if (xv > smax_v) lxv = -pen * (smax_v - xv);

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(64) void k_backward_mfma(Bufs a) {
     const int cur = a.cur[b];
     const double* X = a.X[cur];
     const double* U = a.U[cur];
-    const double reg = d.reg, pen = d.penalty;
+    const double reg = d.reg, pen = d.penalty, pen_xx = d.pen_xx;
     const int lim_on = d.limits_set;
     const int m = AL ? a.m : 0;
 
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(64) void k_backward_mfma(Bufs a) {
                         if (xi > lmx[r]) lq[r] = -pen * (lmx[r] - xi);
                         else if (xi < lmn[r]) lq[r] = -pen * (lmn[r] - xi);
                     } else if (xi > lmx[r] || xi < lmn[r]) {
-                        lq[r] = pen * pen;
+                        lq[r] = pen_xx;
                     }
                 }
         }

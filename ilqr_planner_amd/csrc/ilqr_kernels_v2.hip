@@ -42,12 +42,13 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 template <int NX>
 struct LimRegs {
     int on;
-    double penalty;
+    double penalty, pen_xx;
     double smax[NX], smin[NX];
     int lw[NX];
     __device__ __forceinline__ void load(const DevDesc& d) {
         on = d.limits_set;
         penalty = d.penalty;
+        pen_xx = d.pen_xx;
         UNR for (int i = 0; i < NX; i++) { smax[i] = d.smax[i]; smin[i] = d.smin[i]; lw[i] = d.lw[i]; }
     }
     __device__ __forceinline__ double cost(const double* x) const {
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(64) void k_backward_si(Bufs a) {
                     if (x[i] > lim.smax[i]) { qv = lim.smax[i] - x[i]; L = lim.penalty; }
                     else if (x[i] < lim.smin[i]) { qv = lim.smin[i] - x[i]; L = lim.penalty; }
                     p[i] += -L * qv;
-                    P[sym(i, i)] += L * L;
+                    P[sym(i, i)] += (L != 0.0) ? lim.pen_xx : 0.0;
                 }
             }
         }
@@ -544,7 +545,7 @@ __global__ __launch_bounds__(64) void k_backward_si(Bufs a) {
                     if (x[i] > lim.smax[i]) { qv = lim.smax[i] - x[i]; L = lim.penalty; }
                     else if (x[i] < lim.smin[i]) { qv = lim.smin[i] - x[i]; L = lim.penalty; }
                     lx[i] += -L * qv;
-                    lxxs[sym(i, i)] += L * L;
+                    lxxs[sym(i, i)] += (L != 0.0) ? lim.pen_xx : 0.0;
                 }
             }
         }

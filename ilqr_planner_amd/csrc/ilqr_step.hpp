@@ -47,7 +47,7 @@ ILQR_DEV void stage_derivs(const DevDesc& d, const Bufs& a, int b, const double*
     }
     if (kpi >= 0) {
         double fxv[NF], J[6][DOF], e[NQ], tg[NF], Qe[NQ];
-        fx_of<S, true>(d, x, fxv, J);
+        fx_of<S, true>(d, x, fxv, J, kpi);
         UNR for (int i = 0; i < NF; i++) tg[i] = AT(a.kp_tg, kpi * NF + i, b);
         kp_diff<S>(tg, fxv, e);
         kp_deadzone(d, kpi, e);
@@ -103,7 +103,7 @@ ILQR_DEV void stage_derivs(const DevDesc& d, const Bufs& a, int b, const double*
                 if (x[i] > d.smax[i]) { qv = d.smax[i] - x[i]; L = d.penalty; }
                 else if (x[i] < d.smin[i]) { qv = d.smin[i] - x[i]; L = d.penalty; }
                 lx[i] += -L * qv;
-                lxx[i][i] += L * L;
+                lxx[i][i] += (L != 0.0) ? d.pen_xx : 0.0;  // L^2, once per sub-system of a SequentialSystem
             }
         }
     }

@@ -86,6 +86,19 @@ typedef struct {
     int kp_dist[ILQR_MAX_KP];
     double kp_pos_radius[ILQR_MAX_KP];
     double kp_orn_thresh[ILQR_MAX_KP][3];
+    /* Object frames and sequential systems.  A keypoint whose sub-system drives the robot through a
+     * sim::TransformedSimulationInterface (src/sim/TransformedSimulationInterface.cpp:53-103) sees the pose and the Jacobian in
+     * the frame T = [kp_frame_R | kp_frame_p]: p' = R'(p - t), R_ee' = R' R_ee (Eigen quaternion), J' = blkdiag(R,R)' J.
+     * kp_has_frame[k] = 0: base frame.  sys::SequentialSystem (src/system/SequentialSystem.cpp:78-168) sums the costs of its
+     * sub-systems: every keypoint carries the control penalty of its own sub-system (kp_has_Ru / kp_Ru; the sequential
+     * system's own Rt stays in R_diag for l_u, l_uu) and the limit terms are added once per sub-system (limit_multiplicity;
+     * 0 = 1).  Sub-systems whose keypoints share a timestep are not lowered. */
+    int kp_has_frame[ILQR_MAX_KP];
+    double kp_frame_R[ILQR_MAX_KP][9]; /* row-major */
+    double kp_frame_p[ILQR_MAX_KP][3];
+    int kp_has_Ru[ILQR_MAX_KP];
+    double kp_Ru[ILQR_MAX_KP][ILQR_MAX_NU];
+    int limit_multiplicity;
     double reg;          /* 1e-6 */
     double alpha_floor;  /* 1e-3 */
     double stop_tol;     /* 1e-3 */

@@ -47,7 +47,8 @@ def _tutorial_problem(ctx, case, B=1):
     kps = sorted(pr["keypoints"], key=lambda k: k["timestep"])
     desc = capi.make_desc(kind=kind, nb_deriv=nd, horizon=T, dt=pr["dt"], R_diag=pr["R_diag"], chain=workloads.panda_chain(),
                           kp_timesteps=[k["timestep"] for k in kps], kp_Q=[np.diag(k["Qdiag"]) for k in kps],
-                          limits=dict(state_max=smax, state_min=smin, limit_weight=w, penalty=1.0))
+                          limits=dict(state_max=smax, state_min=smin, limit_weight=w, penalty=1.0),
+                          kp_frames=[k.get("frame") for k in kps], kp_Ru=[k.get("Ru") for k in kps], limit_multiplicity=pr.get("lim_mult", 1))
     p = capi.BatchProblem(ctx, desc, B)
     p.set_init_state(np.tile(pr["q0"], (B, 1)), np.tile(pr["dq0"], (B, 1)))
     for i, k in enumerate(kps):
