@@ -262,6 +262,91 @@ bool KDLRobot::lowerChain(ilqr_problem_desc* d) const {
     std::memcpy(d->seg_axis, chain_.seg_axis, sizeof(chain_.seg_axis));
     return true;
 }
+
+// ---- TransformedSimulationInterface (TransformedSimulationInterface.cpp:20-103)
+TransformedSimulationInterface::TransformedSimulationInterface(const std::shared_ptr<SimulationInterface>& r, const Mat& T) : r_(r), T_(T) {
+    if (!r) throw std::runtime_error("[TransformedSimulationInterface] Object is not initialized");  // :33
+    if (T.rows != 4 || T.cols != 4) throw std::runtime_error("[TransformedSimulationInterface] the frame must be a 4x4 pose matrix");
+    nbCarDim = r->getNbCarDim();
+    dof = r->getDOF();
+    updateKinematics();
+}
+void TransformedSimulationInterface::updateKinematics() {  // :31-47
+    r_->updateKinematics();
+    q = r_->getJointsPos();
+    dq = r_->getJointsVel();
+    Jac = r_->J();
+    x = r_->getEEPosition();
+    ornQuat = r_->getEEOrnQuat();
+    dx = r_->getEEVelocity();
+    w = r_->getEEAngVel();
+    t = r_->getTime();
+}
+void TransformedSimulationInterface::setTime(double time) { t = time; r_->setTime(time); }
+static Vec rot_t(const Mat& T, const Vec& v) {  // R^T v
+    Vec o(3, 0.0);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) o[i] += T(j, i) * v[j];
+    return o;
+}
+Mat TransformedSimulationInterface::J() {  // :53-58  blkdiag(R,R)^T J
+    Mat o(6, Jac.cols);
+    for (int blk = 0; blk < 2; blk++)
+        for (int i = 0; i < 3; i++)
+            for (int c = 0; c < Jac.cols; c++) {
+                double a = 0;
+                for (int l = 0; l < 3; l++) a += T_(l, i) * Jac(3 * blk + l, c);
+                o(3 * blk + i, c) = a;
+            }
+    return o;
+}
+Vec TransformedSimulationInterface::getEEPosition() {  // :67-69
+    return rot_t(T_, Vec{x[0] - T_(0, 3), x[1] - T_(1, 3), x[2] - T_(2, 3)});
+}
+Vec TransformedSimulationInterface::getEEVelocity() { return rot_t(T_, dx); }
+Vec TransformedSimulationInterface::getEEAngVel() { return rot_t(T_, w); }
+Vec TransformedSimulationInterface::getEEOrnQuat() {  // :94-103, Eigen's quaternion <-> matrix conversions
+    const double qw = ornQuat[0], qx = ornQuat[1], qy = ornQuat[2], qz = ornQuat[3];
+    const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
+    const double twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+    const double R[9] = {1 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1 - (txx + tzz), tyz - twx, txz - twy, tyz + twx, 1 - (txx + tyy)};
+    double m[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            double a = 0;
+            for (int l = 0; l < 3; l++) a += T_(l, i) * R[l * 3 + j];
+            m[i * 3 + j] = a;
+        }
+    double tq = m[0] + m[4] + m[8], c[3], qo;
+    if (tq > 0) {
+        tq = std::sqrt(tq + 1.0);
+        qo = 0.5 * tq;
+        tq = 0.5 / tq;
+        c[0] = (m[7] - m[5]) * tq; c[1] = (m[2] - m[6]) * tq; c[2] = (m[3] - m[1]) * tq;
+    } else {
+        int i = 0;
+        if (m[4] > m[0]) i = 1;
+        if (m[8] > m[i * 3 + i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        tq = std::sqrt(m[i * 3 + i] - m[j * 3 + j] - m[k * 3 + k] + 1.0);
+        c[i] = 0.5 * tq;
+        tq = 0.5 / tq;
+        qo = (m[k * 3 + j] - m[j * 3 + k]) * tq;
+        c[j] = (m[j * 3 + i] + m[i * 3 + j]) * tq;
+        c[k] = (m[k * 3 + i] + m[i * 3 + k]) * tq;
+    }
+    return Vec{qo, c[0], c[1], c[2]};
+}
+void TransformedSimulationInterface::sendAcc(double dt, const Vec& ddq, bool updateKin) { r_->sendAcc(dt, ddq, updateKin); updateKinematics(); }
+void TransformedSimulationInterface::sendVel(double dt, const Vec& dq_, bool updateKin) { r_->sendVel(dt, dq_, updateKin); updateKinematics(); }
+void TransformedSimulationInterface::setConfiguration(const Vec& q_, const Vec& dq_, bool reset_time) { r_->setConfiguration(q_, dq_, reset_time); updateKinematics(); }
+bool TransformedSimulationInterface::frame(double* R, double* p) const {
+    for (int i = 0; i < 3; i++) {
+        p[i] = T_(i, 3);
+        for (int j = 0; j < 3; j++) R[i * 3 + j] = T_(i, j);
+    }
+    return true;
+}
 }  // namespace sim
 
 // ------------------------------------------------------------------------------------------------ keypoints
@@ -485,6 +570,90 @@ void System::lower(ilqr_problem_desc* d) const {
             d->kp_pos_radius[k] = df->getPosRadius();
             for (int i = 0; i < 3; i++) d->kp_orn_thresh[k][i] = df->getOrnThresh()[i];
         }
+        if (r->frame(d->kp_frame_R[k], d->kp_frame_p[k])) d->kp_has_frame[k] = 1;  // TransformedSimulationInterface
+    }
+}
+
+// ---- SequentialSystem (SequentialSystem.cpp:20-76)
+SequentialSystem::SequentialSystem(const std::shared_ptr<sim::SimulationInterface>& r_, const std::vector<std::shared_ptr<System>>& systems, const Vec& RtDiag,
+                                   int horizon, int nb_deriv)
+    : System(r_, {}, RtDiag, horizon, nb_deriv, {}), systems_(systems) {
+    if (systems_.empty()) throw std::runtime_error("[SequentialSystem] needs at least one system");
+    auto& s0 = systems_[0];
+    nb_target_var_ = 0;
+    nb_Q_var_ = 0;
+    for (auto& sy : systems_) {
+        nb_target_var_ += sy->getNbTargetVar();
+        nb_Q_var_ += sy->getNbQVar();
+        if (s0->getNbStateVar() != sy->getNbStateVar()) throw std::runtime_error(" All the systems does not have the same number of state variable ");
+        if (s0->getNbCtrlVar() != sy->getNbCtrlVar()) throw std::runtime_error(" All the systems does not have the same number of control variable ");
+        if (s0->getHorizon() != sy->getHorizon()) throw std::runtime_error(" All the systems does not have the same horizon ");
+        if (s0->getNbDeriv() != sy->getNbDeriv()) throw std::runtime_error(" All the systems does not have the same number of derivatives ");
+        if (s0->getInitState() != sy->getInitState()) throw std::runtime_error(" All the systems does not have the same initState ");
+    }
+    nb_state_var_ = s0->getNbStateVar();
+    nb_ctrl_var_ = s0->getNbCtrlVar();
+    horizon_ = s0->getHorizon();
+    nb_deriv_ = s0->getNbDeriv();
+    kind_ = s0->kind();
+    x0_ = s0->getInitState();
+    q0_ = r->getJointsPos();
+    dq0_ = r->getJointsVel();
+    f_x0_.clear();
+    for (auto& sy : systems_) {
+        const Vec f = sy->getInitFoXState();
+        f_x0_.insert(f_x0_.end(), f.begin(), f.end());
+        keypoints.insert(keypoints.end(), sy->getKeypoints().begin(), sy->getKeypoints().end());
+    }
+    init();
+}
+void SequentialSystem::reset() {
+    for (auto& sy : systems_) sy->reset();
+}
+// Device form: dynamics, chain and limits of the first sub-system; every keypoint keeps the frame and the control penalty of
+// its own sub-system; the limit terms count once per sub-system (SequentialSystem.cpp:144-168 sums cost, cost_x, cost_xx).
+void SequentialSystem::lower(ilqr_problem_desc* d) const {
+    std::vector<ilqr_problem_desc> subs(systems_.size());
+    for (size_t i = 0; i < systems_.size(); i++) systems_[i]->lower(&subs[i]);
+    *d = subs[0];
+    if ((int)Rdiag.size() != nb_ctrl_var_) throw std::runtime_error("[System] RtDiag must have nb_ctrl_var entries");
+    for (int i = 0; i < nb_ctrl_var_; i++) d->R_diag[i] = Rdiag[i];  // l_u = R u, l_uu = R use the sequential system's own Rt
+    int n_lim = 0;
+    for (size_t i = 0; i < subs.size(); i++) {
+        const auto& a = subs[i];
+        if (a.kind != d->kind || a.dt != d->dt) throw std::runtime_error("[ilqr_hip] sub-systems of different kinds / dt cannot be lowered");
+        if (a.limits_set != d->limits_set) throw std::runtime_error("[ilqr_hip] sub-systems with and without limits cannot be lowered together");
+        if (a.limits_set) {
+            n_lim++;
+            for (int j = 0; j < nb_state_var_; j++)
+                if (a.state_max[j] != d->state_max[j] || a.state_min[j] != d->state_min[j] || a.limit_weight[j] != d->limit_weight[j] || a.penalty != d->penalty)
+                    throw std::runtime_error("[ilqr_hip] sub-systems with different limits cannot be lowered");
+        }
+    }
+    d->limit_multiplicity = n_lim > 1 ? n_lim : 1;
+    // merge the keypoints by timestep
+    struct Src { int sys, k; };
+    std::vector<Src> order;
+    for (size_t i = 0; i < subs.size(); i++)
+        for (int k = 0; k < subs[i].n_kp; k++) order.push_back({(int)i, k});
+    std::stable_sort(order.begin(), order.end(), [&](const Src& a, const Src& b) { return subs[a.sys].kp_timestep[a.k] < subs[b.sys].kp_timestep[b.k]; });
+    if (order.size() > ILQR_MAX_KP) throw std::runtime_error("[ilqr_hip] too many keypoints for the device descriptor");
+    d->n_kp = (int)order.size();
+    for (size_t o = 0; o < order.size(); o++) {
+        const auto& a = subs[order[o].sys];
+        const int k = order[o].k;
+        if (o > 0 && a.kp_timestep[k] == d->kp_timestep[o - 1])
+            throw std::runtime_error("[ilqr_hip] two keypoints share a timestep: not supported on the device");
+        d->kp_timestep[o] = a.kp_timestep[k];
+        std::memcpy(d->kp_Q[o], a.kp_Q[k], sizeof(a.kp_Q[k]));
+        d->kp_dist[o] = a.kp_dist[k];
+        d->kp_pos_radius[o] = a.kp_pos_radius[k];
+        std::memcpy(d->kp_orn_thresh[o], a.kp_orn_thresh[k], sizeof(a.kp_orn_thresh[k]));
+        d->kp_has_frame[o] = a.kp_has_frame[k];
+        std::memcpy(d->kp_frame_R[o], a.kp_frame_R[k], sizeof(a.kp_frame_R[k]));
+        std::memcpy(d->kp_frame_p[o], a.kp_frame_p[k], sizeof(a.kp_frame_p[k]));
+        d->kp_has_Ru[o] = 1;
+        for (int i = 0; i < nb_ctrl_var_; i++) d->kp_Ru[o][i] = a.R_diag[i];
     }
 }
 

@@ -82,6 +82,8 @@ public:
     virtual void setConfiguration(const Vec& q, const Vec& dq, bool reset_time = true);
     // lowering hook: fill the chain part of the descriptor; false if this simulator cannot run on the device
     virtual bool lowerChain(ilqr_problem_desc*) const { return false; }
+    // object frame this simulator reports poses in (TransformedSimulationInterface): row-major R[9], p[3]; false = base frame
+    virtual bool frame(double*, double*) const { return false; }
 
 protected:
     Vec q, dq, ddq, x, dx, ornQuat, w;
@@ -107,6 +109,28 @@ public:
 protected:
     ilqr_problem_desc chain_;  // only the chain fields are meaningful
     Vec lower_, upper_;
+};
+// The wrapped robot seen from an object frame T (4x4 pose): p' = R'(p - t), R_ee' = R' R_ee, J' = blkdiag(R,R)' J
+// (TransformedSimulationInterface.h / .cpp:20-103).  The Python constructor takes (robot, T) as the reference's binding does.
+class TransformedSimulationInterface : public SimulationInterface {
+public:
+    TransformedSimulationInterface(const std::shared_ptr<SimulationInterface>& r, const Mat& T);
+    void updateKinematics() override;
+    Mat J() override;
+    Vec getEEPosition() override;
+    Vec getEEVelocity() override;
+    Vec getEEAngVel() override;
+    Vec getEEOrnQuat() override;
+    void sendAcc(double dt, const Vec& ddq, bool updateKin = true) override;
+    void sendVel(double dt, const Vec& dq, bool updateKin = true) override;
+    void setConfiguration(const Vec& q, const Vec& dq, bool reset_time = true) override;
+    void setTime(double time) override;
+    bool lowerChain(ilqr_problem_desc* d) const override { return r_->lowerChain(d); }
+    bool frame(double* R, double* p) const override;
+
+protected:
+    std::shared_ptr<SimulationInterface> r_;
+    Mat T_;
 };
 }  // namespace sim
 
@@ -202,6 +226,9 @@ public:
     // per-instance pieces for B = 1: q0, dq0 captured by localInit
     Vec q0() const { return q0_; }
     Vec dq0() const { return dq0_; }
+    int getNbDeriv() const { return nb_deriv_; }
+    const Vec& Rt() const { return Rdiag; }
+    int kind() const { return kind_; }
 
 protected:
     void init();
@@ -248,6 +275,20 @@ public:
 
 protected:
     void localInit();
+};
+// Sum of the costs of several Systems sharing one robot (SequentialSystem.h / .cpp:20-168): dynamics of the first, keypoints of
+// all (each in its own sub-system's frame, with that sub-system's control penalty), limit terms once per sub-system.
+class SequentialSystem : public System {
+public:
+    SequentialSystem(const std::shared_ptr<sim::SimulationInterface>& r, const std::vector<std::shared_ptr<System>>& systems, const Vec& RtDiag,
+                     int horizon, int nb_deriv);
+    Vec getState() override { return systems_.at(0)->getState(); }
+    void reset() override;
+    void lower(ilqr_problem_desc* d) const override;
+    const std::vector<std::shared_ptr<System>>& systems() const { return systems_; }
+
+protected:
+    std::vector<std::shared_ptr<System>> systems_;
 };
 }  // namespace sys
 

@@ -127,6 +127,9 @@ PYBIND11_MODULE(PyLQR, m) {
              py::arg("tip_frame"), py::arg("q"), py::arg("dq"))
         .def("joint_lower_limits", &sim::KDLRobot::jointLowerLimits)
         .def("joint_upper_limits", &sim::KDLRobot::jointUpperLimits);
+    // bindings.cpp:206-207: TransformedSimulationInterface(r, T)
+    py::class_<sim::TransformedSimulationInterface, sim::SimulationInterface, std::shared_ptr<sim::TransformedSimulationInterface>>(m_sim, "TransformedSimulationInterface")
+        .def(py::init<const std::shared_ptr<sim::SimulationInterface>&, const Mat&>(), py::arg("r"), py::arg("T"));
 
     // ------------------------------------------------------------------ system
     py::module m_sys = m.def_submodule("system");
@@ -179,6 +182,10 @@ PYBIND11_MODULE(PyLQR, m) {
         .def(py::init<const SimP&, const KPs&, const Vec&, const Vec&, const Vec&, int, int>(), py::arg("r"), py::arg("keypoints"), py::arg("RtDiag"),
              py::arg("qMax"), py::arg("qMin"), py::arg("horizon"), py::arg("nbDeriv"))
         .def(py::init<const SimP&, const KPs&, const Vec&, int, int>(), py::arg("r"), py::arg("keypoints"), py::arg("RtDiag"), py::arg("horizon"), py::arg("nbDeriv"));
+    // bindings.cpp:505-507: SequentialSystem(r, systems, RtDiag, horizon, nbDeriv)
+    py::class_<sys::SequentialSystem, sys::System, std::shared_ptr<sys::SequentialSystem>>(m_sys, "SequentialSystem")
+        .def(py::init<const SimP&, const std::vector<std::shared_ptr<sys::System>>&, const Vec&, int, int>(), py::arg("r"), py::arg("systems"), py::arg("RtDiag"),
+             py::arg("horizon"), py::arg("nbDeriv"));
 
     // ------------------------------------------------------------------ utils (before solver: CallBackMessage is an argument type)
     py::module m_ut = m.def_submodule("utils");

@@ -156,3 +156,89 @@ def test_constructor_errors_match_reference():
         PosOrnTimePlannerSys(rbt, [kp1], [1e-5] * 8, 20, 1)
     with pytest.raises(RuntimeError, match=r"Wrong keypoint order \(nb_deriv_\): Expecting 2 got 1"):  # System.cpp:369
         PosOrnPlannerSys(rbt, [kp1], [1e-5] * 7, 20, 2, 0.1)
+
+
+def _frame_objs():
+    """obj1_frame / obj2_frame of POS_ORN_SYS_OBJ_FRAME.ipynb / POS_ORN_MULTI_SYS.ipynb cell 8 (the fixture holds the 4x4 poses)."""
+    g = golden()["cases"]["POS_ORN_MULTI_SYS"]["problem"]["keypoints"]
+    return np.array(g[0]["frame"]), np.array(g[1]["frame"])
+
+
+def test_obj_frame_tutorial(capsys):
+    """POS_ORN_SYS_OBJ_FRAME.ipynb: one PosOrnPlannerSys on a TransformedSimulationInterface (cells 10-19)."""
+    from PyLQR.sim import KDLRobot, TransformedSimulationInterface
+    from PyLQR.solver import BatchILQRCP, ILQRRecursive
+    from PyLQR.system import PosOrnKeypoint, PosOrnPlannerSys
+    from PyLQR.utils import PythonCallbackMessage, primitives
+
+    g = golden()["cases"]["POS_ORN_SYS_OBJ_FRAME"]
+    dof, nb_ctrl_var, horizon, dt = 7, 7, 400, 0.01
+    q0, dq0 = g["problem"]["q0"], [0] * dof
+    qMax, dqMax = np.array([np.pi] * dof) * 10, np.array([10] * dof)
+    obj1_frame, _ = _frame_objs()
+    rbt = KDLRobot(URDF, "panda_link0", "panda_tip", q0, dq0)
+    transformed_robot = TransformedSimulationInterface(rbt, obj1_frame)
+    # the wrapper reports the pose in the object frame
+    R, t = obj1_frame[:3, :3], obj1_frame[:3, 3]
+    np.testing.assert_allclose(transformed_robot.get_ee_pos(), R.T @ (np.asarray(rbt.get_ee_pos()) - t), atol=1e-14)
+    np.testing.assert_allclose(transformed_robot.J(), np.kron(np.eye(2), R.T) @ np.asarray(rbt.J()), atol=1e-14)
+    kps = [PosOrnKeypoint(np.array(k["pos"]), np.array(k["orn"]), np.diag(k["Qdiag"]), k["timestep"]) for k in g["problem"]["keypoints"]]
+    cmd_penalties = (np.ones(nb_ctrl_var) * 1e-5).tolist()
+    sys_ = PosOrnPlannerSys(transformed_robot, kps, cmd_penalties, qMax, -qMax, dqMax, -dqMax, horizon, 1, dt)
+    u0 = np.tile(np.array([0] * nb_ctrl_var), horizon - 1)
+    PSI = np.kron(primitives.build_psi_unitstep(horizon - 1, 2), np.identity(nb_ctrl_var))
+    planner1, planner2 = BatchILQRCP(sys_, PSI), ILQRRecursive(sys_)
+    cb = PythonCallbackMessage()
+    capsys.readouterr()
+    U1 = planner1.solve(25, u0, True, cb)
+    _check_stream(capsys.readouterr().out.strip().splitlines(), g["solves"][0]["trace"])
+    assert np.asarray(U1).size == (horizon - 1) * nb_ctrl_var
+    X2, F_X2, U2, K2, k2, cost = planner2.solve(u0.reshape((-1, nb_ctrl_var)), 10, True, True, cb)
+    _check_stream(capsys.readouterr().out.strip().splitlines(), g["solves"][1]["trace"])
+    # replay on the host simulator, pose read through the wrapper: the end effector reaches the target expressed in the object frame
+    transformed_robot.set_conf(q0, dq0, True)
+    for u in np.asarray(U2):
+        transformed_robot.send_vel(dt, u, True)
+    np.testing.assert_allclose(transformed_robot.get_ee_pos(), kps[1].get_position(), atol=5e-3)
+
+
+def test_multi_sys_tutorial(capsys):
+    """POS_ORN_MULTI_SYS.ipynb: SequentialSystem of two PosOrnPlannerSys, each in its own object frame (cells 10-23)."""
+    from PyLQR.sim import KDLRobot, TransformedSimulationInterface
+    from PyLQR.solver import ILQRRecursive
+    from PyLQR.system import PosOrnKeypoint, PosOrnPlannerSys, SequentialSystem
+    from PyLQR.utils import PythonCallbackMessage
+
+    g = golden()["cases"]["POS_ORN_MULTI_SYS"]
+    dof, nb_ctrl_var, horizon, dt = 7, 7, 600, 0.01
+    q0, dq0 = g["problem"]["q0"], [0] * dof
+    qMax, dqMax = np.array([np.pi] * dof) * 10, np.array([10] * dof)
+    obj1_frame, obj2_frame = _frame_objs()
+    rbt = KDLRobot(URDF, "panda_link0", "panda_tip", q0, dq0)
+    tr1, tr2 = TransformedSimulationInterface(rbt, obj1_frame), TransformedSimulationInterface(rbt, obj2_frame)
+    cmd_penalties = (np.ones(nb_ctrl_var) * 1e-5).tolist()
+    k1, k2_ = g["problem"]["keypoints"]
+    sys1 = PosOrnPlannerSys(tr1, [PosOrnKeypoint(np.array(k1["pos"]), np.array(k1["orn"]), np.diag(k1["Qdiag"]), k1["timestep"])], cmd_penalties,
+                            qMax, -qMax, dqMax, -dqMax, horizon, 1, dt)
+    sys2 = PosOrnPlannerSys(tr2, [PosOrnKeypoint(np.array(k2_["pos"]), np.array(k2_["orn"]), np.diag(k2_["Qdiag"]), k2_["timestep"])], cmd_penalties,
+                            qMax, -qMax, dqMax, -dqMax, horizon, 1, dt)
+    sys_ = SequentialSystem(rbt, [sys1, sys2], cmd_penalties, horizon, 1)
+    assert (sys_.get_nb_state_var(), sys_.get_nb_ctrl_var(), sys_.get_nb_target_var(), sys_.get_horizon()) == (7, 7, 14, 600)
+    planner2 = ILQRRecursive(sys_)
+    cb = PythonCallbackMessage()
+    capsys.readouterr()
+    u0 = np.tile(np.array([0] * nb_ctrl_var), horizon - 1)
+    X2, F_X2, U2, K2, k2, cost = planner2.solve(u0.reshape((-1, nb_ctrl_var)), 10, True, True, cb)
+    _check_stream(capsys.readouterr().out.strip().splitlines(), g["solves"][1]["trace"])
+    # replay: at T/2 the tool is at target 1 of object frame 1, at the end at target 2 of object frame 2
+    rbt.set_conf(q0, dq0, True)
+    U2 = np.asarray(U2)
+    for i in range(horizon - 1):
+        if i == k1["timestep"]:
+            np.testing.assert_allclose(tr1.get_ee_pos(), k1["pos"], atol=5e-3)
+        rbt.send_vel(dt, U2[i], True)
+        tr1.update_kinematics()
+    tr2.update_kinematics()
+    np.testing.assert_allclose(tr2.get_ee_pos(), k2_["pos"], atol=5e-3)
+    with pytest.raises(RuntimeError):  # SequentialSystem.cpp:36-56
+        SequentialSystem(rbt, [sys1, PosOrnPlannerSys(tr2, [], cmd_penalties, qMax, -qMax, dqMax, -dqMax, horizon + 1, 1, dt)], cmd_penalties, horizon, 1)
