@@ -139,8 +139,7 @@ cases["POS_ORN_MULTI_SYS"] = dict(  # SequentialSystem(rbt, [sys1 in obj1_frame 
     problem=frame_problem(600, 0.01, [
         dict(timestep=300, pos=[0, 0, -0.15], orn=[1, 0, 0, 0], Qdiag=[1, 1, 1, 0, 0, 0], frame=OBJ1, Ru=[1e-5] * 7),
         dict(timestep=599, pos=[0.1, 0.1, -0.1], orn=[1, 0, 0, 0], Qdiag=[1, 1, 1, 0, 0, 0], frame=OBJ2, Ru=[1e-5] * 7)], 2),
-    # the BatchILQRCP solve of this notebook (stacked residuals of both sub-systems) is not restated: its trace is kept for later
-    solves=[dict(solver="BatchILQRCP_sequential", psi=dict(kind="unitstep", K=2), nb_iter=25, early_stop=True, **t[0]),
+    solves=[dict(solver="BatchILQRCP", psi=dict(kind="unitstep", K=2), nb_iter=25, early_stop=True, **t[0]),
             dict(solver="ILQRRecursive", nb_iter=10, line_search=True, early_stop=True, **t[1])])
 
 # FK literals stored in the notebooks (POS_ORN_MULTI_SYS.ipynb cell 8: pose of the tutorial q0, incl. negative w)

@@ -224,10 +224,16 @@ def test_multi_sys_tutorial(capsys):
                             qMax, -qMax, dqMax, -dqMax, horizon, 1, dt)
     sys_ = SequentialSystem(rbt, [sys1, sys2], cmd_penalties, horizon, 1)
     assert (sys_.get_nb_state_var(), sys_.get_nb_ctrl_var(), sys_.get_nb_target_var(), sys_.get_horizon()) == (7, 7, 14, 600)
+    from PyLQR.solver import BatchILQRCP
+    from PyLQR.utils import primitives
+
     planner2 = ILQRRecursive(sys_)
     cb = PythonCallbackMessage()
     capsys.readouterr()
     u0 = np.tile(np.array([0] * nb_ctrl_var), horizon - 1)
+    PSI = np.kron(primitives.build_psi_unitstep(horizon - 1, 2), np.identity(nb_ctrl_var))
+    BatchILQRCP(sys_, PSI).solve(25, u0, True, cb)
+    _check_stream(capsys.readouterr().out.strip().splitlines(), g["solves"][0]["trace"])
     X2, F_X2, U2, K2, k2, cost = planner2.solve(u0.reshape((-1, nb_ctrl_var)), 10, True, True, cb)
     _check_stream(capsys.readouterr().out.strip().splitlines(), g["solves"][1]["trace"])
     # replay: at T/2 the tool is at target 1 of object frame 1, at the end at target 2 of object frame 2

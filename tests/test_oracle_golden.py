@@ -8,7 +8,7 @@ import pytest
 from tests.helpers import assert_trace, golden, oracle_system, orc, panda_segs, psi_of, u0_of
 
 G = golden()
-CASES = [(n, i) for n, c in G["cases"].items() for i, s in enumerate(c["solves"]) if s["solver"] not in ("BatchILQR", "BatchILQRCP_sequential")]
+CASES = [(n, i) for n, c in G["cases"].items() for i, s in enumerate(c["solves"]) if s["solver"] != "BatchILQR"]
 
 
 def test_fk_literal_from_notebook():
@@ -68,7 +68,7 @@ def test_trace(name, idx):
 
 def test_initial_costs():
     # initial costs printed by the CP solver = cost of the zero-control rollout (SURVEY.md 8c KATs)
-    for name, c0 in (("POS_ORN_SYS", 0.506613), ("POS_ORN_TIME_SYS", 3.41273), ("POS_ORN_TIME_SYS_2ND", 4.04153), ("POS_ORN_SYS_OBJ_FRAME", 1.11617)):
+    for name, c0 in (("POS_ORN_SYS", 0.506613), ("POS_ORN_TIME_SYS", 3.41273), ("POS_ORN_TIME_SYS_2ND", 4.04153), ("POS_ORN_SYS_OBJ_FRAME", 1.11617), ("POS_ORN_MULTI_SYS", 0.174263)):
         case = G["cases"][name]
         s = oracle_system(case["problem"])
         sv = [x for x in case["solves"] if x["solver"] == "BatchILQRCP"][0]
