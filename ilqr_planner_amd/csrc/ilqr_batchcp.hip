@@ -13,6 +13,7 @@
 // pay; it is VALU work and the pass is bound by the rollout, like the recursive solver.
 #include "ilqr_batchcp.hpp"
 
+#include <cstdlib>
 #include <cstring>
 
 #include "ilqr_step.hpp"
@@ -308,6 +309,184 @@ __global__ __launch_bounds__(64) void k_cp_final(Bufs a) {
     UNR for (int i = 0; i < NX; i++) AT(a.X[0], (T - 1) * NX + i, b) = x[i];
 }
 
+// ------------------------------------------------------------------------------------------------ PosOrn systems: coefficient space
+// For constant A, B the controls stay in the affine family u = u0 + PSI w and the trajectory is affine in w:
+//     x_t(w) = x_t(u0) + Wt_t w,   Wt_{i+1} = A Wt_i + B PSI_i  (Wt_0 = 0; the TRUE sensitivity, not the reference's shifted Su)
+//     sum_k u_k' R u_k = u0'R u0 + 2 w.(PSI'R u0) + w'(PSI'R PSI) w,   ||PSI dw||^2 = dw'(PSI'PSI) dw,   PSI'R u = PSI'R u0 + (PSI'R PSI) w
+// so an iteration needs the states at the keypoint steps only: no pass over the horizon at all.  The shifted W = Su PSI of the
+// reference (what H and g are built from, quirk D-1) is the same for every instance and is broadcast once; k_cp_solve is shared
+// with the general path.  The horizon is walked twice per solve: k_cpl_init (rollout of u0) and k_cpl_final (u, X out).
+#define WT(kp, which, r, q) c.wt[((((size_t)(kp) * 2 + (which)) * NX + (r)) * KWP) + (q)]
+
+template <class S, int KWP>
+ILQR_DEV void cpl_states(const DevDesc& d, const CPArgs& c, int b, int kpi, const double* w, double* x, double* xp) {
+    constexpr int NX = S::NX;
+    const int Bp = d.Bp;
+    const double* xb = c.xbk + (size_t)kpi * 2 * NX * Bp;
+    UNR for (int r = 0; r < NX; r++) {
+        double s0 = AT(xb, r, b), s1 = AT(xb, NX + r, b);
+        UNR for (int q = 0; q < KWP; q++) { s0 += WT(kpi, 0, r, q) * w[q]; s1 += WT(kpi, 1, r, q) * w[q]; }
+        x[r] = s0;
+        xp[r] = s1;
+    }
+}
+// e'Qe at the keypoints + limit term of the pre-step states + control cost, all as functions of w (BatchILQRCP.cpp:135,150)
+template <class S, int KWP>
+ILQR_DEV double cpl_cost(const DevDesc& d, const Bufs& a, const CPArgs& c, int b, const double* w, const double* g0, double c00) {
+    constexpr int NX = S::NX;
+    const int Bp = d.Bp;
+    double cost_e = 0, cost_l = 0;
+    for (int kpi = 0; kpi < d.n_kp; kpi++) {
+        double x[NX], xp[NX], tg[S::NF];
+        cpl_states<S, KWP>(d, c, b, kpi, w, x, xp);
+        UNR for (int r = 0; r < S::NF; r++) tg[r] = AT(a.kp_tg, kpi * S::NF + r, b);
+        cost_e += kp_cost<S>(d, kpi, tg, x, nullptr);
+        if (d.kp_t[kpi] > 0) {
+            double Ld[NX], ql[NX];
+            limit_terms<S>(d, xp, Ld, ql);
+            UNR for (int r = 0; r < NX; r++) cost_l += ql[r] * Ld[r] * ql[r];
+        }
+    }
+    double lin = 0, quad = 0;
+    UNR for (int q = 0; q < KWP; q++) {
+        double s = 0;
+        UNR for (int r = 0; r < KWP; r++) s += c.H0[q * KWP + r] * w[r];
+        lin += g0[q] * w[q];
+        quad += w[q] * s;
+    }
+    // the padded diagonal of H0 is 1 (keeps H regular); the padded w entries are 0, so it adds nothing
+    return cost_e + ((c00 + 2 * lin) + quad) + cost_l;
+}
+
+template <class S, int KWP>
+__global__ __launch_bounds__(64) void k_cpl_init(Bufs a, CPArgs c) {
+    constexpr int NX = S::NX, NU = S::NU;
+    const DevDesc& d = *a.desc;
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= d.B) return;
+    const int Bp = d.Bp, T = d.T;
+    double x[NX], xp[NX], u[NU], xn[NX], g0[KWP];
+    UNR for (int q = 0; q < KWP; q++) g0[q] = 0;
+    init_state<S>(d, a, b, x);
+    UNR for (int i = 0; i < NX; i++) xp[i] = x[i];
+    double c00 = 0;
+    int kpi = 0;
+    auto record = [&]() {
+        double* xb = c.xbk + (size_t)kpi * 2 * NX * Bp;
+        UNR for (int r = 0; r < NX; r++) { AT(xb, r, b) = x[r]; AT(xb, NX + r, b) = xp[r]; }
+        kpi++;
+    };
+    if (kpi < d.n_kp && d.kp_t[kpi] == 0) record();
+    for (int s = 0; s < T - 1; s++) {
+        UNR for (int i = 0; i < NU; i++) {
+            u[i] = AT(a.U0, s * NU + i, b);
+            const double ru = d.R_diag[i] * u[i];
+            c00 += u[i] * ru;
+            UNR for (int q = 0; q < KWP; q++) g0[q] += PSI(s * NU + i, q) * ru;
+        }
+        dyn_step<S>(d, x, u, xn);
+        UNR for (int i = 0; i < NX; i++) { xp[i] = x[i]; x[i] = xn[i]; }
+        if (kpi < d.n_kp && d.kp_t[kpi] == s + 1) record();
+    }
+    UNR for (int q = 0; q < KWP; q++) { AT(c.g0, q, b) = g0[q]; AT(c.wv, q, b) = 0; }
+    c.c00[b] = c00;
+    a.cur[b] = 0;
+    a.active[b] = 1;
+    a.iters[b] = 0;
+    a.status[b] = 0;
+    a.alpha[b] = 1.0;
+    a.pend[b] = 0;
+    a.pred[b] = 0;
+}
+
+// the reference's W = Su PSI at the keypoint steps is the same for all instances of an LTI system: fill the per-instance table
+// k_cp_solve reads (one lane per (instance, entry))
+__global__ void k_cpl_bcast(const double* __restrict__ wref, double* __restrict__ Wkp, int n_entries, int B, int Bp) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x, e = blockIdx.y;
+    if (b < B && e < n_entries) Wkp[(size_t)e * Bp + b] = wref[e];
+}
+
+template <class S, int KWP>
+__global__ __launch_bounds__(64) void k_cpl_linearize(Bufs a, CPArgs c) {
+    constexpr int NX = S::NX;
+    const DevDesc& d = *a.desc;
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= d.B || !a.active[b]) return;
+    const int Bp = d.Bp;
+    double w[KWP], g0[KWP];
+    UNR for (int q = 0; q < KWP; q++) { w[q] = AT(c.wv, q, b); g0[q] = AT(c.g0, q, b); }
+    for (int kpi = 0; kpi < d.n_kp; kpi++) {
+        double x[NX], xp[NX], lxx[NX][NX], lx[NX], Ld[NX], ql[NX];
+        cpl_states<S, KWP>(d, c, b, kpi, w, x, xp);
+        stage_derivs<S, false>(d, a, b, x, kpi, lxx, lx);  // lxx = J'QJ, lx = -J'Q e
+        if (d.kp_t[kpi] > 0) limit_terms<S>(d, xp, Ld, ql);
+        else { UNR for (int r = 0; r < NX; r++) { Ld[r] = 0; ql[r] = 0; } }
+        double* Ck = c.Ckp + (size_t)kpi * NX * NX * Bp;
+        double* rk = c.rkp + (size_t)kpi * NX * Bp;
+        UNR for (int r = 0; r < NX; r++) {
+            UNR for (int s = 0; s < NX; s++) AT(Ck, r * NX + s, b) = lxx[r][s] + ((r == s) ? Ld[r] : 0.0);
+            AT(rk, r, b) = -lx[r] + Ld[r] * ql[r];
+        }
+    }
+    a.cost[b] = cpl_cost<S, KWP>(d, a, c, b, w, g0, c.c00[b]);  // cost0 of this iteration (BatchILQRCP.cpp:135)
+    UNR for (int q = 0; q < KWP; q++) {  // PSI'R u = PSI'R u0 + (PSI'R PSI) w   (padded rows of H0: identity x 0)
+        double s = g0[q];
+        UNR for (int r = 0; r < KWP; r++) s += ((q < c.Kw && r < c.Kw) ? c.H0[q * KWP + r] : 0.0) * w[r];
+        AT(c.gu, q, b) = s;
+    }
+}
+
+template <class S, int KWP>
+__global__ __launch_bounds__(64) void k_cpl_linesearch(Bufs a, CPArgs c) {
+    const DevDesc& d = *a.desc;
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= d.B || !a.active[b]) return;
+    const int Bp = d.Bp;
+    double w[KWP], dw[KWP], g0[KWP], wn[KWP];
+    UNR for (int q = 0; q < KWP; q++) { w[q] = AT(c.wv, q, b); dw[q] = AT(c.dw, q, b); g0[q] = AT(c.g0, q, b); }
+    double dun2 = 0;  // sum_k ||PSI_k dw||^2
+    UNR for (int q = 0; q < KWP; q++) {
+        double s = 0;
+        UNR for (int r = 0; r < KWP; r++) s += c.pp[q * KWP + r] * dw[r];
+        dun2 += dw[q] * s;
+    }
+    const double cost0 = a.cost[b], c00 = c.c00[b];
+    double alpha = 1.0, cost = 0;
+    while (true) {  // BatchILQRCP.cpp:138-158
+        UNR for (int q = 0; q < KWP; q++) wn[q] = w[q] + alpha * dw[q];
+        cost = cpl_cost<S, KWP>(d, a, c, b, wn, g0, c00);
+        if ((cost < cost0) || (alpha < 1e-3)) break;
+        alpha /= 2;
+    }
+    UNR for (int q = 0; q < KWP; q++) AT(c.wv, q, b) = wn[q];
+    a.alpha[b] = alpha;
+    a.iters[b] = c.it + 1;
+    a.status[b] = (isfinite(cost) ? 0 : 1) | ((alpha < 1e-3) ? 2 : 0);
+    if (a.cost_trace) {
+        a.cost_trace[(size_t)c.it * Bp + b] = cost0;  // the reference prints the PRE-step cost (BatchILQRCP.cpp:160)
+        a.alpha_trace[(size_t)c.it * Bp + b] = alpha;
+    }
+    a.cost[b] = cost;
+    if (c.early_stop && alpha * sqrt(dun2 > 0 ? dun2 : 0.0) < 1e-3) a.active[b] = 0;  // :167
+}
+
+// u = u0 + PSI w, then the rollout that fills X (k_cp_final)
+template <class S, int KWP>
+__global__ __launch_bounds__(64) void k_cpl_controls(Bufs a, CPArgs c) {
+    constexpr int NU = S::NU;
+    const DevDesc& d = *a.desc;
+    const int b = blockIdx.x * 64 + threadIdx.x, s = blockIdx.y;
+    if (b >= d.B) return;
+    const int Bp = d.Bp;
+    double w[KWP];
+    UNR for (int q = 0; q < KWP; q++) w[q] = AT(c.wv, q, b);
+    UNR for (int i = 0; i < NU; i++) {
+        double du = 0;
+        UNR for (int q = 0; q < KWP; q++) du += PSI(s * NU + i, q) * w[q];
+        AT(a.U[0], s * NU + i, b) = AT(a.U0, s * NU + i, b) + du;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 
 template <class T>
@@ -352,6 +531,73 @@ static int run_cp(BatchCPState& st, const DevDesc& h, Bufs& bufs, int nb_iter, i
     return 0;
 }
 
+// PosOrn systems: iterate in coefficient space (see the kernels above).  psip = PSI padded to KWP columns (host copy).
+template <class S, int KWP>
+static int run_cpl(BatchCPState& st, const DevDesc& h, Bufs& bufs, const std::vector<double>& psip, int nb_iter, int early_stop, hipStream_t stream,
+                   std::string& err) {
+    constexpr int NX = S::NX, NU = S::NU, ND = S::ND;
+    const int B = h.B, T = h.T, nkp = h.n_kp;
+    const double dt = h.dt, hdt2 = dt * dt / 2;
+    // sensitivities by their recurrences (constant A, B): Wt_{i+1} = A Wt_i + B PSI_i from Wt_0 = 0 (true), and the reference's
+    // shifted one Wr_{i+1} = A Wr_i + B PSI_i from Wr_1 = 0, i >= 1 (BatchILQRCP.cpp:61-97, quirk D-1)
+    auto advance = [&](std::vector<double>& W, int i) {
+        for (int q = 0; q < KWP; q++) {
+            if (ND == 2) for (int r = 0; r < DOF; r++) W[r * KWP + q] += dt * W[(DOF + r) * KWP + q];
+            for (int r = 0; r < DOF; r++) {
+                const double ps = psip[((size_t)i * NU + r) * KWP + q];
+                if (ND == 1) W[r * KWP + q] += dt * ps;
+                else { W[r * KWP + q] += hdt2 * ps; W[(DOF + r) * KWP + q] += dt * ps; }
+            }
+        }
+    };
+    std::vector<std::vector<double>> Wt(T, std::vector<double>(NX * KWP, 0.0)), Wr(T, std::vector<double>(NX * KWP, 0.0));
+    for (int i = 0; i + 1 < T; i++) { Wt[i + 1] = Wt[i]; advance(Wt[i + 1], i); }
+    for (int i = 1; i + 1 < T; i++) { Wr[i + 1] = Wr[i]; advance(Wr[i + 1], i); }
+    std::vector<double> wt((size_t)(nkp > 0 ? nkp : 1) * 2 * NX * KWP, 0.0), wref((size_t)(nkp > 0 ? nkp : 1) * NX * KWP, 0.0), pp((size_t)KWP * KWP, 0.0);
+    for (int t = 0; t < nkp; t++) {
+        const int ts = h.kp_t[t];
+        std::copy(Wt[ts].begin(), Wt[ts].end(), wt.begin() + ((size_t)t * 2 + 0) * NX * KWP);
+        if (ts > 0) std::copy(Wt[ts - 1].begin(), Wt[ts - 1].end(), wt.begin() + ((size_t)t * 2 + 1) * NX * KWP);
+        std::copy(Wr[ts].begin(), Wr[ts].end(), wref.begin() + (size_t)t * NX * KWP);
+    }
+    const int rows = (T - 1) * NU;
+    for (int a_ = 0; a_ < KWP; a_++)
+        for (int b_ = 0; b_ < KWP; b_++) {
+            double s = 0;
+            for (int k = 0; k < rows; k++) s += psip[(size_t)k * KWP + a_] * psip[(size_t)k * KWP + b_];
+            pp[(size_t)a_ * KWP + b_] = s;
+        }
+    if (hipMemcpyAsync(st.wt, wt.data(), wt.size() * sizeof(double), hipMemcpyHostToDevice, stream) != hipSuccess ||
+        hipMemcpyAsync(st.wref, wref.data(), wref.size() * sizeof(double), hipMemcpyHostToDevice, stream) != hipSuccess ||
+        hipMemcpyAsync(st.pp, pp.data(), pp.size() * sizeof(double), hipMemcpyHostToDevice, stream) != hipSuccess ||
+        hipStreamSynchronize(stream) != hipSuccess) {
+        err = "ilqr_solve_batch_cp: sensitivity upload failed";
+        return 1;
+    }
+    const dim3 grid((B + 63) / 64), block(64);
+    const size_t lds_h = sizeof(double) * KWP * KWP * 64;
+    if (hipFuncSetAttribute((const void*)k_cp_solve<S, KWP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h) != hipSuccess) {
+        err = "ilqr_solve_batch_cp: cannot reserve LDS";
+        return 1;
+    }
+    CPArgs c;
+    c.psi = st.psi; c.H0 = st.H0; c.Wkp = st.Wkp; c.Ckp = st.Ckp; c.rkp = st.rkp; c.gu = st.gu; c.dw = st.dw; c.dun = st.dun;
+    c.wt = st.wt; c.pp = st.pp; c.wv = st.wv; c.g0 = st.g0; c.c00 = st.c00; c.xbk = st.xbk;
+    c.Kw = st.Kw; c.early_stop = early_stop; c.n_alpha = 11; c.it = 0;
+    hipLaunchKernelGGL((k_cpl_init<S, KWP>), grid, block, 0, stream, bufs, c);
+    if (nkp > 0) hipLaunchKernelGGL(k_cpl_bcast, dim3((B + 255) / 256, nkp * NX * KWP), dim3(256), 0, stream, st.wref, st.Wkp, nkp * NX * KWP, B, h.Bp);
+    for (int it = 0; it < nb_iter; it++) {
+        c.it = it;
+        hipLaunchKernelGGL((k_cpl_linearize<S, KWP>), grid, block, 0, stream, bufs, c);
+        hipLaunchKernelGGL((k_cp_solve<S, KWP>), grid, block, lds_h, stream, bufs, c);
+        hipLaunchKernelGGL((k_cpl_linesearch<S, KWP>), grid, block, 0, stream, bufs, c);
+    }
+    hipLaunchKernelGGL((k_cpl_controls<S, KWP>), dim3((B + 63) / 64, T - 1), block, 0, stream, bufs, c);
+    hipLaunchKernelGGL((k_cp_final<S>), grid, block, 0, stream, bufs);
+    if (hipGetLastError() != hipSuccess) { err = "ilqr_solve_batch_cp: kernel launch failed"; return 1; }
+    return 0;
+}
+
 int batchcp_solve(BatchCPState& st, const DevDesc& h, Bufs& bufs, int nx, int nu, int nf, int nq, const double* psi_host, int Kw,
                   int nb_iter, int early_stop, hipStream_t stream, std::string& err) {
     (void)nf; (void)nq;
@@ -365,7 +611,10 @@ int batchcp_solve(BatchCPState& st, const DevDesc& h, Bufs& bufs, int nx, int nu
         bool ok = cp_alloc(st, &st.psi, (size_t)rows * KWP, stream) && cp_alloc(st, &st.H0, (size_t)KWP * KWP, stream) &&
                   cp_alloc(st, &st.Wkp, (size_t)nkp * nx * KWP * Bp, stream) && cp_alloc(st, &st.Ckp, (size_t)nkp * nx * nx * Bp, stream) &&
                   cp_alloc(st, &st.rkp, (size_t)nkp * nx * Bp, stream) && cp_alloc(st, &st.gu, (size_t)KWP * Bp, stream) &&
-                  cp_alloc(st, &st.dw, (size_t)KWP * Bp, stream) && cp_alloc(st, &st.dun, (size_t)Bp, stream);
+                  cp_alloc(st, &st.dw, (size_t)KWP * Bp, stream) && cp_alloc(st, &st.dun, (size_t)Bp, stream) &&
+                  cp_alloc(st, &st.wt, (size_t)nkp * 2 * nx * KWP, stream) && cp_alloc(st, &st.pp, (size_t)KWP * KWP, stream) && cp_alloc(st, &st.wref, (size_t)nkp * nx * KWP, stream) &&
+                  cp_alloc(st, &st.wv, (size_t)KWP * Bp, stream) && cp_alloc(st, &st.g0, (size_t)KWP * Bp, stream) &&
+                  cp_alloc(st, &st.c00, (size_t)Bp, stream) && cp_alloc(st, &st.xbk, (size_t)nkp * 2 * nx * Bp, stream);
         if (!ok) { batchcp_free(st); err = "ilqr_solve_batch_cp: hipMalloc failed"; return 1; }
         st.KWP = KWP; st.nkp = nkp; st.nx = nx; st.Bp = Bp; st.rows = rows;
     }
@@ -387,6 +636,9 @@ int batchcp_solve(BatchCPState& st, const DevDesc& h, Bufs& bufs, int nx, int nu
         err = "ilqr_solve_batch_cp: PSI upload failed";
         return 1;
     }
+    static const bool general = std::getenv("ILQR_CP") && !std::strcmp(std::getenv("ILQR_CP"), "general");  // cross-check path
+    if (h.kind == 0 && h.nd == 1 && !general) return run_cpl<Sys<0, 1>, 16>(st, h, bufs, psip, nb_iter, early_stop, stream, err);
+    if (h.kind == 0 && h.nd == 2 && !general) return run_cpl<Sys<0, 2>, 16>(st, h, bufs, psip, nb_iter, early_stop, stream, err);
     if (h.kind == 0 && h.nd == 1) return run_cp<Sys<0, 1>, 16>(st, h, bufs, nb_iter, early_stop, stream, err);
     if (h.kind == 0 && h.nd == 2) return run_cp<Sys<0, 2>, 16>(st, h, bufs, nb_iter, early_stop, stream, err);
     if (h.kind == 1 && h.nd == 1) return run_cp<Sys<1, 1>, 16>(st, h, bufs, nb_iter, early_stop, stream, err);

@@ -20,6 +20,14 @@ struct BatchCPState {
     double* gu = nullptr;   // [KWP][Bp]          PSI' R u
     double* dw = nullptr;   // [KWP][Bp]
     double* dun = nullptr;  // [Bp]               ||du||
+    // coefficient-space path of the PosOrn systems (constant A, B): u = u0 + PSI w
+    double* wt = nullptr;   // [n_kp][2][NX][KWP] true sensitivities d x_t / d w and d x_{t-1} / d w at the keypoint steps (shared)
+    double* pp = nullptr;   // [KWP][KWP]         PSI' PSI (shared)
+    double* wref = nullptr; // [n_kp][NX][KWP]    the reference's shifted W = Su PSI at the keypoint steps (shared; broadcast into Wkp)
+    double* wv = nullptr;   // [KWP][Bp]          w
+    double* g0 = nullptr;   // [KWP][Bp]          PSI' R u0
+    double* c00 = nullptr;  // [Bp]               u0' R u0
+    double* xbk = nullptr;  // [n_kp][2][NX][Bp]  x_t, x_{t-1} of the rollout of u0
     std::vector<void*> allocs;
 };
 
@@ -28,6 +36,8 @@ struct CPArgs {
     const double* psi;
     const double* H0;
     double *Wkp, *Ckp, *rkp, *gu, *dw, *dun;
+    const double *wt, *pp;
+    double *wv, *g0, *c00, *xbk;
     int Kw, it, early_stop, n_alpha;
 };
 
