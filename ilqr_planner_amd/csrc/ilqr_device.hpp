@@ -369,12 +369,14 @@ ILQR_DEV double limit_cost(const DevDesc& d, const double* x) {
 }
 
 // System::cost at a keypoint step (System.cpp:213-234) -- task part only
-template <class S>
+// EXT = false: plain PosOrn / Spacetime keypoints in the base frame (no dead zone, no object frame, the system's R): the lean
+// instantiation the hot kernels use when the descriptor has none of those (FwdArgs::kp_ext)
+template <class S, bool EXT = true>
 ILQR_DEV double kp_cost(const DevDesc& d, int kpi, const double* tg, const double* x, const double* u) {
     double fxv[S::NF], e[S::NQ];
-    fx_of<S, false>(d, x, fxv, nullptr, kpi);
+    fx_of<S, false>(d, x, fxv, nullptr, EXT ? kpi : -1);
     kp_diff<S>(tg, fxv, e);
-    kp_deadzone(d, kpi, e);
+    if (EXT) kp_deadzone(d, kpi, e);
     const double* Q = d.kp_Q[kpi];
     double c = 0;
 #pragma unroll
@@ -387,7 +389,7 @@ ILQR_DEV double kp_cost(const DevDesc& d, int kpi, const double* tg, const doubl
     double ru = 0;
     if (u) {
 #pragma unroll
-        for (int i = 0; i < S::NU; i++) ru += u[i] * (d.kp_has_Ru[kpi] ? d.kp_Ru[kpi][i] : d.R_diag[i]) * u[i];
+        for (int i = 0; i < S::NU; i++) ru += u[i] * ((EXT && d.kp_has_Ru[kpi]) ? d.kp_Ru[kpi][i] : d.R_diag[i]) * u[i];
     }
     return c + ru;
 }

@@ -52,6 +52,7 @@ struct FwdArgs {
     int n_alpha;  // number of step sizes 1, 1/2, ... the line search may try (11 for alpha_floor = 1e-3)
     double penalty_roll, penalty_update;
     int dbg;      // experiment switches (ILQR_DBG), 0 in production
+    int kp_ext;   // some keypoint has a dead zone, an object frame or its own control penalty (selects the full keypoint code)
 };
 
 // v1 (one lane per instance, generic): KER_INIT, KER_BACKWARD, KER_FORWARD

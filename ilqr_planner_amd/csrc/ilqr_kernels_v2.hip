@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void k_al_post(Bufs a, FwdArgs f) {
 // l_x, l_xx of the keypoint steps (System::cost_x / cost_xx incl. the limit terms) for the current trajectory, one lane per
 // (instance, keypoint).  Keeps FK, the quaternion log map and J'QJ out of the sequential sweep: the sweep only loads
 // NX + NX*NX doubles at the (two) keypoint steps.
-template <class S>
+template <class S, bool EXT>
 __global__ __launch_bounds__(64) void k_kp_derivs(Bufs a) {
     constexpr int NX = S::NX;
     const DevDesc& d = *a.desc;
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(64) void k_kp_derivs(Bufs a) {
     const double* X = a.X[a.cur[b]];
     double x[NX], lxx[NX][NX], lx[NX];
     UNR for (int i = 0; i < NX; i++) x[i] = AT(X, k * NX + i, b);
-    stage_derivs<S>(d, a, b, x, kpi, lxx, lx);
+    stage_derivs<S, true, EXT>(d, a, b, x, kpi, lxx, lx);
     double* out = a.kpd + (size_t)kpi * (NX + NX * NX) * Bp;
     UNR for (int i = 0; i < NX; i++) {
         AT(out, i, b) = lx[i];
@@ -596,7 +596,8 @@ static void launch_v2_kernel(int which, const Bufs& a, int B, int T, hipStream_t
             hipLaunchKernelGGL((k_al_post<S>), dim3((B + 255) / 256, T - 1), dim3(256), 0, st, a, f);
             break;
         case KER_KP_DERIVS:
-            if (f.n_kp > 0) hipLaunchKernelGGL((k_kp_derivs<S>), dim3((B + 63) / 64, f.n_kp), dim3(64), 0, st, a);
+            if (f.n_kp > 0 && f.kp_ext) hipLaunchKernelGGL((k_kp_derivs<S, true>), dim3((B + 63) / 64, f.n_kp), dim3(64), 0, st, a);
+            else if (f.n_kp > 0) hipLaunchKernelGGL((k_kp_derivs<S, false>), dim3((B + 63) / 64, f.n_kp), dim3(64), 0, st, a);
             break;
     }
 }

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(512) void k_forward_wg(Bufs a, FwdArgs f) {
 // steps + the limit cost k_forward_w32 accumulated; the first alpha (descending) whose cost is below the current one wins, else
 // the last one tried (ILQRRecursive.cpp:101-155).  Writes cost/alpha/iters/status/traces, `pend` for k_blend/k_flip, and the
 // early-stop flag.
-template <class S, int NA>
+template <class S, int NA, bool EXT>
 __global__ __launch_bounds__(64) void k_select(Bufs a, FwdArgs f) {
     constexpr int NX = S::NX, NU = S::NU;
     static_assert(NA <= 16, "16 lanes per instance");
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(64) void k_select(Bufs a, FwdArgs f) {
             UNR for (int i = 0; i < NX; i++) xt[i] = fma(aa, AT(dv, i, bb), AT(Xb, k * NX + i, bb));
             UNR for (int i = 0; i < NU; i++) ut[i] = (k < T - 1) ? fma(aa, AT(dv, NX + i, bb), AT(Ub, k * NU + i, bb)) : 0.0;
             UNR for (int i = 0; i < S::NF; i++) tg[i] = AT(a.kp_tg, kpi * S::NF + i, bb);
-            c += kp_cost<S>(d, kpi, tg, xt, ut);
+            c += kp_cost<S, EXT>(d, kpi, tg, xt, ut);
         }
         c += AT(a.lsc, al, bb);
     }
@@ -470,13 +470,16 @@ void launch_forward_wave(const Bufs& a, int B, hipStream_t st, const FwdArgs& f)
     const dim3 sgrid((B + 3) / 4), sblock(64);
     if (f.n_alpha <= 1) {
         hipLaunchKernelGGL((k_forward_wg<1>), grid, block, 0, st, a, f);
-        hipLaunchKernelGGL((k_select<S, 1>), sgrid, sblock, 0, st, a, f);
+        if (f.kp_ext) hipLaunchKernelGGL((k_select<S, 1, true>), sgrid, sblock, 0, st, a, f);
+        else hipLaunchKernelGGL((k_select<S, 1, false>), sgrid, sblock, 0, st, a, f);
     } else if (f.n_alpha <= 11) {
         hipLaunchKernelGGL((k_forward_wg<11>), grid, block, 0, st, a, f);
-        hipLaunchKernelGGL((k_select<S, 11>), sgrid, sblock, 0, st, a, f);
+        if (f.kp_ext) hipLaunchKernelGGL((k_select<S, 11, true>), sgrid, sblock, 0, st, a, f);
+        else hipLaunchKernelGGL((k_select<S, 11, false>), sgrid, sblock, 0, st, a, f);
     } else {
         hipLaunchKernelGGL((k_forward_wg<16>), grid, block, 0, st, a, f);
-        hipLaunchKernelGGL((k_select<S, 16>), sgrid, sblock, 0, st, a, f);
+        if (f.kp_ext) hipLaunchKernelGGL((k_select<S, 16, true>), sgrid, sblock, 0, st, a, f);
+        else hipLaunchKernelGGL((k_select<S, 16, false>), sgrid, sblock, 0, st, a, f);
     }
 }
 
