@@ -80,8 +80,13 @@ extern "C" void ilqr_desc_defaults(ilqr_problem_desc* d) {
 
 extern "C" int ilqr_dims_of(const ilqr_problem_desc* d, ilqr_dims* o) {
     if (!d || !o) return 1;
-    if (d->kind != ILQR_SYS_POS_ORN && d->kind != ILQR_SYS_POS_ORN_TIME) return 1;
+    if (d->kind != ILQR_SYS_POS_ORN && d->kind != ILQR_SYS_POS_ORN_TIME && d->kind != ILQR_SYS_JOINT) return 1;
     if (d->nb_deriv != 1 && d->nb_deriv != 2) return 1;
+    if (d->kind == ILQR_SYS_JOINT) {  // JointSpacePlannerSys.cpp:71-74; its 2nd-order variant is dimensionally inconsistent upstream
+        if (d->nb_deriv != 1) return 1;
+        o->n_x = o->n_u = o->n_f = o->n_Q = d->dof;
+        return 0;
+    }
     const int tm = d->kind == ILQR_SYS_POS_ORN_TIME ? 1 : 0;
     o->n_x = d->nb_deriv * d->dof + tm;  // PosOrnPlannerSys.cpp:74 / PosOrnTimePlannerSys.cpp:67
     o->n_u = d->dof + tm;
@@ -231,7 +236,7 @@ static int lower_desc(ilqr_ctx* c, const ilqr_problem_desc& d, int B, int Bp, De
     ilqr_dims dm;
     if (ilqr_dims_of(&d, &dm)) return fail(c, "unsupported system kind / nb_deriv");
     std::memset(&h, 0, sizeof(h));
-    if (lower_chain(c, d, h.chain)) return 1;
+    if (!(d.kind == ILQR_SYS_JOINT && d.n_seg == 0) && lower_chain(c, d, h.chain)) return 1;  // joint-space systems need no chain
     if (d.horizon < 2) return fail(c, "horizon must be >= 2");
     h.kind = d.kind; h.nd = d.nb_deriv; h.T = d.horizon; h.B = B; h.Bp = Bp; h.dt = d.dt;
     for (int i = 0; i < dm.n_u; i++) h.R_diag[i] = d.R_diag[i];
@@ -481,7 +486,7 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
     const char* fwd_env = std::getenv("ILQR_FWD");
     const bool fwd_rows = fwd_tile && forward_rows_supported(kind, nd, n_alpha) && !(fwd_env && !std::strcmp(fwd_env, "tile"));
     const bool fwd_lin = fwd_rows && !(fwd_env && !std::strcmp(fwd_env, "rows"));  // linear line search (PosOrn systems)
-    const bool fwd_wave = fwd_lin && forward_wave_supported(kind, nd, n_alpha);  // 32 lanes per instance + k_select
+    const bool fwd_wave = fwd_tile && forward_wave_supported(kind, nd, n_alpha) && !(fwd_env && (!std::strcmp(fwd_env, "tile") || !std::strcmp(fwd_env, "rows")));  // 32 lanes per instance + k_select
     const bool bwd_si = (path == 2) && backward_si_supported(kind, nd, al, p->bufs.m, p->bufs.per_step, p->con_state_only);
     const bool bwd_mfma = (path == 2) && !bwd_si && backward_mfma_supported(kind, nd, al, p->bufs.m);  // wave per instance, f64 matrix cores
     const bool bwd_gen = (path == 2) && !bwd_si && !bwd_mfma && backward_gen_supported(kind, nd, al, p->bufs.m);  // same, VALU + LDS products
@@ -493,7 +498,7 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
     {
         ProfScope ps(c, ILQR_PROF_ROLLOUT);
         if (path != 1 && init_lti_supported(kind, nd)) {
-            launch_init_lti(nd, p->bufs, p->B, c->stream);
+            launch_init_lti(kind, nd, p->bufs, p->B, c->stream);
             if (al) {  // active-set weights of the initial trajectory: I_k = penalty * (g<0 && lambda==0 ? 0 : 1)
                 f.it = -1; f.do_update = 0;
                 launch_solver_v2(kind, nd, KER_AL_UPDATE, al, p->bufs, p->B, p->T, c->stream, f);
@@ -523,14 +528,14 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
         if (fwd_tile) {
             {
                 ProfScope ps(c, ILQR_PROF_FORWARD);
-                if (fwd_wave) launch_forward_wave(p->bufs, p->B, c->stream, f);
+                if (fwd_wave) launch_forward_wave(kind, p->bufs, p->B, c->stream, f);
                 else if (fwd_lin) launch_forward_lin(nd, KER_FWD_SPEC, p->bufs, p->B, p->T, c->stream, f);
                 else if (fwd_rows) launch_forward_rows(nd, KER_FWD_SPEC, p->bufs, p->B, c->stream, f);
                 else launch_solver_v2(kind, nd, KER_FWD_SPEC, al, p->bufs, p->B, p->T, c->stream, f);
             }
             if (fwd_wave) {  // winner applied, AL bookkeeping and buffer flip in one pass over the trajectory
                 ProfScope ps(c, ILQR_PROF_APPLY);
-                launch_apply_wave(p->bufs, p->B, p->T, c->stream, f);
+                launch_apply_wave(kind, p->bufs, p->B, p->T, c->stream, f);
             } else if (fwd_rows) {  // the cost pass writes no trajectory: the winner is always re-rolled
                 ProfScope ps(c, ILQR_PROF_APPLY);
                 if (fwd_lin) launch_forward_lin(nd, KER_FWD_APPLY, p->bufs, p->B, p->T, c->stream, f);

@@ -54,11 +54,14 @@ struct DevDesc {
 
 template <int KIND_, int ND_>
 struct Sys {
+    // KIND 0 = PosOrnPlannerSys, 1 = PosOrnTimePlannerSys, 2 = JointSpacePlannerSys (target space = state space, J = I;
+    // JointSpacePlannerSys.cpp:71-81, nb_deriv = 1 only: the reference's 2nd-order variant is dimensionally inconsistent)
     static constexpr int KIND = KIND_, ND = ND_, TM = (KIND_ == 1) ? 1 : 0;
+    static constexpr bool JOINT = (KIND_ == 2);
     static constexpr int NX = ND_ * DOF + TM;
     static constexpr int NU = DOF + TM;
-    static constexpr int NF = 7 * ND_ + TM;
-    static constexpr int NQ = NF - ND_;
+    static constexpr int NF = JOINT ? NX : 7 * ND_ + TM;
+    static constexpr int NQ = JOINT ? NX : NF - ND_;
 };
 
 #define ILQR_DEV __device__ __forceinline__
@@ -238,6 +241,11 @@ ILQR_DEV void eig_mat_to_quat(const double* m, double* q) {
 // f(x) of getFxJac: [p; quat (; dp; dquat) (; t)]  and the 6x7 Jacobian block (the full J is blkdiag(J,J) bordered by 1)
 template <class S, bool WANT_J>
 ILQR_DEV void fx_of(const DevDesc& d, const double* x, double* fxv, double (*J)[DOF], int kpi = -1) {
+    if (S::JOINT) {  // JointSpacePlannerSys::getFxJac: f(x) = x (J = I is applied by the callers)
+#pragma unroll
+        for (int i = 0; i < S::NF; i++) fxv[i] = x[i];
+        return;
+    }
     double Jl[6][DOF];
     double (*Jp)[DOF] = (WANT_J || S::ND == 2) ? (WANT_J ? J : Jl) : nullptr;
     if (WANT_J || S::ND == 2) fk<true>(d.chain, x, fxv, fxv + 3, Jp);
@@ -298,6 +306,11 @@ ILQR_DEV void fx_of(const DevDesc& d, const double* x, double* fxv, double (*J)[
 // Keypoint::diff: tg is the target in f(x) layout
 template <class S>
 ILQR_DEV void kp_diff(const double* tg, const double* fxv, double* e) {
+    if (S::JOINT) {  // AngularKeypoint::diff (AngularKeypoint.cpp:24-27): target - state
+#pragma unroll
+        for (int i = 0; i < S::NQ; i++) e[i] = tg[i] - fxv[i];
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < S::NQ; i++) e[i] = 0;
     bool allz = true;

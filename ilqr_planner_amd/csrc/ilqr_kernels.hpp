@@ -76,9 +76,9 @@ void launch_forward_rows(int nd, int which, const Bufs& a, int B, hipStream_t st
 void launch_forward_lin(int nd, int which, const Bufs& a, int B, int T, hipStream_t st, const FwdArgs& f);
 bool forward_wave_supported(int kind, int nd, int n_alpha);
 bool init_lti_supported(int kind, int nd);
-void launch_init_lti(int nd, const Bufs& a, int B, hipStream_t st);  // followed by KER_AL_UPDATE (it = -1) for AL solves
-void launch_forward_wave(const Bufs& a, int B, hipStream_t st, const FwdArgs& f);
-void launch_apply_wave(const Bufs& a, int B, int T, hipStream_t st, const FwdArgs& f);  // blend + AL bookkeeping + flip
+void launch_init_lti(int kind, int nd, const Bufs& a, int B, hipStream_t st);  // followed by KER_AL_UPDATE (it = -1) for AL solves
+void launch_forward_wave(int kind, const Bufs& a, int B, hipStream_t st, const FwdArgs& f);
+void launch_apply_wave(int kind, const Bufs& a, int B, int T, hipStream_t st, const FwdArgs& f);  // blend + AL bookkeeping + flip
 void launch_fx_all(int kind, int nd, const Bufs& a, int B, int T, double* out, hipStream_t st);
 void launch_to_soa(const double* src, double* dst, int B, int Bp, int rows, hipStream_t st);
 void launch_from_soa(const double* src, double* dst, int B, int Bp, int rows, hipStream_t st);

@@ -372,8 +372,8 @@ __global__ __launch_bounds__(64) void k_backward_gen(Bufs a) {
 
 bool backward_gen_supported(int kind, int nd, bool al, int m) {
     static const bool off = std::getenv("ILQR_BWD") && !std::strcmp(std::getenv("ILQR_BWD"), "v1");
-    (void)kind; (void)nd;
-    return !off && (!al || m <= 16);
+    (void)nd;
+    return !off && kind != 2 && (!al || m <= 16);
 }
 
 template <class S>

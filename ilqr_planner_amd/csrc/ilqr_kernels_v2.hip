@@ -605,7 +605,7 @@ static void launch_v2_kernel(int which, const Bufs& a, int B, int T, hipStream_t
 // closed-form sweep: usable for PosOrn nb_deriv=1 when no constraint row touches the controls, rows are shared over k
 // and there are at most 4 of them (they live in registers)
 bool backward_si_supported(int kind, int nd, bool al, int m, int per_step, bool con_state_only) {
-    if (kind != 0 || nd != 1) return false;
+    if (!((kind == 0 || kind == 2) && nd == 1)) return false;  // single-integrator dynamics: PosOrn-1 and JointSpace-1
     if (!al) return true;
     return con_state_only && per_step == 0 && m <= 4;
 }
@@ -621,7 +621,8 @@ void launch_solver_v2(int kind, int nd, int which, bool al, const Bufs& a, int B
         else hipLaunchKernelGGL((k_backward_si<4>), grid, block, 0, st, a);
         return;
     }
-    if (kind == 0 && nd == 1) launch_v2_kernel<Sys<0, 1>>(which, a, B, T, st, f);
+    if (kind == 2) launch_v2_kernel<Sys<2, 1>>(which, a, B, T, st, f);
+    else if (kind == 0 && nd == 1) launch_v2_kernel<Sys<0, 1>>(which, a, B, T, st, f);
     else if (kind == 0 && nd == 2) launch_v2_kernel<Sys<0, 2>>(which, a, B, T, st, f);
     else if (kind == 1 && nd == 1) launch_v2_kernel<Sys<1, 1>>(which, a, B, T, st, f);
     else launch_v2_kernel<Sys<1, 2>>(which, a, B, T, st, f);

@@ -370,7 +370,7 @@ __global__ void k_flip_ran(Bufs a) {
 // task cost at the keypoints (one lane per instance) and sets the bookkeeping; the AL weights come from k_al_post.
 template <class S>
 __global__ __launch_bounds__(256) void k_init_roll_lti(Bufs a) {
-    static_assert(S::KIND == 0, "PosOrn systems");
+    static_assert(S::TM == 0, "constant-dt systems (PosOrn, JointSpace)");
     constexpr int NX = S::NX, NU = S::NU, ND = S::ND, CH = 8;
     const DevDesc& d = *a.desc;
     const int b = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(64) void k_init_finish(Bufs a) {
 
 bool init_lti_supported(int kind, int nd) {
     static const bool off = std::getenv("ILQR_INIT") && !std::strcmp(std::getenv("ILQR_INIT"), "v1");
-    return !off && kind == 0 && (nd == 1 || nd == 2);
+    return !off && ((kind == 0 && (nd == 1 || nd == 2)) || (kind == 2 && nd == 1));
 }
 
 template <class S>
@@ -448,39 +448,51 @@ static void launch_init_lti_sys(const Bufs& a, int B, hipStream_t st) {
     hipLaunchKernelGGL((k_init_roll_lti<S>), dim3((B + 255) / 256, DOF), dim3(256), 0, st, a);
     hipLaunchKernelGGL((k_init_finish<S>), dim3((B + 63) / 64), dim3(64), 0, st, a);
 }
-void launch_init_lti(int nd, const Bufs& a, int B, hipStream_t st) {
-    if (nd == 1) launch_init_lti_sys<Sys<0, 1>>(a, B, st);
+void launch_init_lti(int kind, int nd, const Bufs& a, int B, hipStream_t st) {
+    if (kind == 2) launch_init_lti_sys<Sys<2, 1>>(a, B, st);
+    else if (nd == 1) launch_init_lti_sys<Sys<0, 1>>(a, B, st);
     else launch_init_lti_sys<Sys<0, 2>>(a, B, st);
 }
 
 bool forward_wave_supported(int kind, int nd, int n_alpha) {
     static const bool off = std::getenv("ILQR_FWD") && !std::strcmp(std::getenv("ILQR_FWD"), "lin");
-    return !off && kind == 0 && nd == 1 && n_alpha <= 16;
+    return !off && (kind == 0 || kind == 2) && nd == 1 && n_alpha <= 16;
 }
 
-void launch_apply_wave(const Bufs& a, int B, int T, hipStream_t st, const FwdArgs& f) {
-    using S = Sys<0, 1>;
+template <class S>
+static void launch_apply_wave_sys(const Bufs& a, int B, int T, hipStream_t st, const FwdArgs& f) {
     hipLaunchKernelGGL((k_apply<S>), dim3((B + 15) / 16, (T + 15) / 16), dim3(256), 0, st, a, f);
     hipLaunchKernelGGL(k_flip_ran, dim3((B + 255) / 256), dim3(256), 0, st, a);
 }
+void launch_apply_wave(int kind, const Bufs& a, int B, int T, hipStream_t st, const FwdArgs& f) {
+    if (kind == 2) launch_apply_wave_sys<Sys<2, 1>>(a, B, T, st, f);
+    else launch_apply_wave_sys<Sys<0, 1>>(a, B, T, st, f);
+}
 
-void launch_forward_wave(const Bufs& a, int B, hipStream_t st, const FwdArgs& f) {
-    using S = Sys<0, 1>;
-    const dim3 grid(grid_x8((B + 15) / 16)), block(512);
+template <class S, int NA>
+static void launch_select(const Bufs& a, int B, hipStream_t st, const FwdArgs& f) {
     const dim3 sgrid((B + 3) / 4), sblock(64);
+    if (f.kp_ext) hipLaunchKernelGGL((k_select<S, NA, true>), sgrid, sblock, 0, st, a, f);
+    else hipLaunchKernelGGL((k_select<S, NA, false>), sgrid, sblock, 0, st, a, f);
+}
+// the rollout itself knows no keypoint function (single-integrator dynamics); the decision kernel is per system kind
+template <class S>
+static void launch_forward_wave_sys(const Bufs& a, int B, hipStream_t st, const FwdArgs& f) {
+    const dim3 grid(grid_x8((B + 15) / 16)), block(512);
     if (f.n_alpha <= 1) {
         hipLaunchKernelGGL((k_forward_wg<1>), grid, block, 0, st, a, f);
-        if (f.kp_ext) hipLaunchKernelGGL((k_select<S, 1, true>), sgrid, sblock, 0, st, a, f);
-        else hipLaunchKernelGGL((k_select<S, 1, false>), sgrid, sblock, 0, st, a, f);
+        launch_select<S, 1>(a, B, st, f);
     } else if (f.n_alpha <= 11) {
         hipLaunchKernelGGL((k_forward_wg<11>), grid, block, 0, st, a, f);
-        if (f.kp_ext) hipLaunchKernelGGL((k_select<S, 11, true>), sgrid, sblock, 0, st, a, f);
-        else hipLaunchKernelGGL((k_select<S, 11, false>), sgrid, sblock, 0, st, a, f);
+        launch_select<S, 11>(a, B, st, f);
     } else {
         hipLaunchKernelGGL((k_forward_wg<16>), grid, block, 0, st, a, f);
-        if (f.kp_ext) hipLaunchKernelGGL((k_select<S, 16, true>), sgrid, sblock, 0, st, a, f);
-        else hipLaunchKernelGGL((k_select<S, 16, false>), sgrid, sblock, 0, st, a, f);
+        launch_select<S, 16>(a, B, st, f);
     }
+}
+void launch_forward_wave(int kind, const Bufs& a, int B, hipStream_t st, const FwdArgs& f) {
+    if (kind == 2) launch_forward_wave_sys<Sys<2, 1>>(a, B, st, f);
+    else launch_forward_wave_sys<Sys<0, 1>>(a, B, st, f);
 }
 
 }  // namespace ilqr

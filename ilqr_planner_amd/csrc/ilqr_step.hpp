@@ -45,7 +45,18 @@ ILQR_DEV void stage_derivs(const DevDesc& d, const Bufs& a, int b, const double*
         lx[i] = 0;
         UNR for (int j = 0; j < NX; j++) lxx[i][j] = 0;
     }
-    if (kpi >= 0) {
+    if (kpi >= 0 && S::JOINT) {  // J = I: l_x = -Q e, l_xx = Q
+        double e[NQ], tg[NF];
+        UNR for (int i = 0; i < NF; i++) tg[i] = AT(a.kp_tg, kpi * NF + i, b);
+        kp_diff<S>(tg, x, e);
+        const double* Q = d.kp_Q[kpi];
+        UNR for (int i = 0; i < NQ; i++) {
+            double s = 0;
+            UNR for (int j = 0; j < NQ; j++) s += Q[i * NQ + j] * e[j];
+            lx[i] += -1 * s;
+            UNR for (int j = 0; j < NQ; j++) lxx[i][j] += Q[i * NQ + j];
+        }
+    } else if (kpi >= 0) {
         double fxv[NF], J[6][DOF], e[NQ], tg[NF], Qe[NQ];
         fx_of<S, true>(d, x, fxv, J, EXT ? kpi : -1);
         UNR for (int i = 0; i < NF; i++) tg[i] = AT(a.kp_tg, kpi * NF + i, b);

@@ -28,6 +28,12 @@ def config(name: str):
     P = [1, 1, 1, .1, .1, .1]
     V = [1, 1, 1, .1, .1, .1]
     cfgs = {
+        # C1: the reference's CPU plumbing case -- Robot2D (3 links) + JointSpacePlannerSys, T = 50, one seed.  On the device the
+        # 3 joints are padded to the 7 the kernels are built for (zero precision, zero limit weight, u = 0 keeps them at rest).
+        "C1": dict(kind=capi.SYS_JOINT, nb_deriv=1, T=50, dt=0.1, B=1, seed=0, dof=3, q0=[np.pi / 4] * 3, Qdiag=[[1, 1, 1]] * 2, solver="recursive",
+                   nb_iter=10),
+        "C1j": dict(kind=capi.SYS_JOINT, nb_deriv=1, T=100, dt=0.1, B=256, seed=10, dof=7, Qdiag=[[1] * 7, [1, .5, 1, .5, 1, .5, 1]], solver="recursive",
+                    nb_iter=8),
         # C2: "pos-only" = zero orientation precision (POS_ORN_MULTI_SYS.ipynb cell 12)
         "C2": dict(kind=capi.SYS_POS_ORN, nb_deriv=1, T=100, dt=0.1, B=256, seed=1, Qdiag=[[1, 1, 1, 0, 0, 0]] * 2, solver="recursive", nb_iter=20),
         # C3: AL-iLQR with the tutorial's single row q_6 <= 2.0 (penalty .25, scaling 1.1, update every 5)
@@ -58,6 +64,8 @@ def make_batch(ctx: capi.Context, cfg: dict, B: int | None = None, seed: int | N
     """Returns (desc, inputs) where inputs = dict(q0, dq0, targets[list per keypoint], U0, [A, b, lambda0])."""
     B = int(B if B is not None else cfg["B"])
     seed = int(seed if seed is not None else cfg["seed"])
+    if cfg["kind"] == capi.SYS_JOINT:
+        return _make_joint_batch(cfg, B, seed, limits)
     chain = chain or panda_chain()
     dof = chain["dof"]
     lo, up = chain["lower"], chain["upper"]
@@ -99,6 +107,35 @@ def make_batch(ctx: capi.Context, cfg: dict, B: int | None = None, seed: int | N
         A = np.zeros((1, nx + nu))
         A[0, al["row"]] = 1.0
         inp.update(A=A, b=np.array([al["bound"]]), lambda0=np.full((B, T - 1, 1), al["bound"]))  # tutorial: init multipliers = b
+    return desc, inp
+
+
+def _make_joint_batch(cfg, B, seed, limits):
+    """JointSpacePlannerSys batches (AngularKeypoint targets); `dof` < 7 joints are padded to the device's 7."""
+    rng = np.random.default_rng(seed)
+    T, dofu, D = cfg["T"], cfg.get("dof", 7), 7
+    kp_t = [T // 2 - 1, T - 1]
+    lim = 10 * np.pi if limits == "inactive" else 2.0
+    smax, smin, w = np.zeros(D), np.zeros(D), np.zeros(D, dtype=int)
+    smax[:dofu], smin[:dofu], w[:dofu] = lim, -lim, 1
+    chain = dict(dof=D, seg_joint=[], seg_xyz=[], seg_R=[], seg_axis=[])  # no kinematic chain: f(x) = x
+    kp_Q = []
+    for q in cfg["Qdiag"]:
+        Q = np.zeros((D, D))
+        Q[:dofu, :dofu] = np.diag(q)
+        kp_Q.append(Q)
+    desc = capi.make_desc(kind=capi.SYS_JOINT, nb_deriv=1, horizon=T, dt=cfg["dt"], R_diag=[1e-5] * D, chain=chain, kp_timesteps=kp_t, kp_Q=kp_Q,
+                          limits=dict(state_max=smax, state_min=smin, limit_weight=w, penalty=1.0))
+    q0 = np.zeros((B, D))
+    base = np.asarray(cfg.get("q0", [0.0] * dofu), float)
+    q0[:, :dofu] = base[None, :] + (rng.uniform(-0.3, 0.3, (B, dofu)) if B > 1 else 0.0)
+    targets = []
+    for _ in range(2):
+        t = np.zeros((B, D))
+        t[:, :dofu] = rng.uniform(-2.5, 2.5, (B, dofu))
+        targets.append(t)
+    inp = dict(q0=q0, dq0=np.zeros((B, D)), targets=targets, U0=np.zeros((B, T - 1, D)), kp_t=kp_t, dof=dofu,
+               limits=dict(state_max=smax, state_min=smin, limit_weight=w))
     return desc, inp
 
 

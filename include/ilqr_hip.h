@@ -38,6 +38,8 @@ extern "C" {
 /* system kinds: which sys::System subclass is being lowered */
 #define ILQR_SYS_POS_ORN 0      /* sys::PosOrnPlannerSys      (src/system/PosOrnPlannerSys.cpp) */
 #define ILQR_SYS_POS_ORN_TIME 1 /* sys::PosOrnTimePlannerSys  (src/system/PosOrnTimePlannerSys.cpp) */
+#define ILQR_SYS_JOINT 2        /* sys::JointSpacePlannerSys  (src/system/JointSpacePlannerSys.cpp), nb_deriv = 1: target space = joint
+                                   space, J = I, AngularKeypoint targets (n_f = n_Q = dof); no chain needed (n_seg may be 0) */
 
 /* per-instance status word */
 #define ILQR_STATUS_OK 0

@@ -252,6 +252,10 @@ void orc_system_finalize(orc_system* s) {
     s->n_u = s->dof + tm;                /* :75 / :68 */
     s->n_f = 7 * s->nb_deriv + tm;       /* :76 / :69 */
     s->n_Q = s->n_f - s->nb_deriv;       /* :77 / :70 */
+    if (s->kind == ORC_SYS_JOINT) {      /* JointSpacePlannerSys.cpp:71-74: target space = state space */
+        s->n_f = s->n_x;
+        s->n_Q = s->n_x;
+    }
 }
 
 /* getFxJac(xk): System.cpp:163-179 + PosOrnPlannerSys.cpp:80-102 ; PosOrnTimePlannerSys.cpp:85-137.
@@ -294,6 +298,14 @@ static void eig_mat_to_quat(const double m[9], double q[4]) {
  * dx' = R' dx, w' = R' w. */
 static void fx_jac_frame(const orc_system* s, const orc_keypoint* kp, const double* x, double* fx, double* J) {
     int dof = s->dof, nd = s->nb_deriv, tm = (s->kind == ORC_SYS_POS_ORN_TIME);
+    if (s->kind == ORC_SYS_JOINT) { /* JointSpacePlannerSys::getFxJac, JointSpacePlannerSys.cpp:77-81: f(x) = x, J = I */
+        if (fx) memcpy(fx, x, sizeof(double) * s->n_f);
+        if (J) {
+            memset(J, 0, sizeof(double) * s->n_Q * s->n_x);
+            for (int i = 0; i < s->n_Q && i < s->n_x; i++) J[i * s->n_x + i] = 1;
+        }
+        return;
+    }
     double p[3], quat[4], Jac[6 * ORC_MAX_DOF], dx[3], w[3], dq0[ORC_MAX_DOF] = {0};
     const double* dq = (nd == 2) ? x + dof : dq0;
     orc_fk(&s->chain, x, dq, p, quat, Jac, dx, w);
@@ -355,6 +367,10 @@ void orc_get_fx_jac(const orc_system* s, const double* x, double* fx, double* J)
 /* PosOrnKeypoint::diff (PosOrnKeypoint.cpp:24-45), SpacetimeKeypoint::diff (SpacetimeKeypoint.cpp:19-25) */
 void orc_kp_diff(const orc_system* s, const orc_keypoint* kp, const double* fx, double* e) {
     int nd = s->nb_deriv, tm = (s->kind == ORC_SYS_POS_ORN_TIME);
+    if (s->kind == ORC_SYS_JOINT) { /* AngularKeypoint::diff, AngularKeypoint.cpp:24-27: target - state */
+        for (int i = 0; i < s->n_Q; i++) e[i] = kp->jt[i] - fx[i];
+        return;
+    }
     int nst = 7 * nd;
     memset(e, 0, sizeof(double) * s->n_Q);
     if (!is_zero(fx, nst)) { /* :29 */

@@ -32,7 +32,7 @@ extern "C" {
 #define ORC_MAX_KP 8
 #define ORC_MAX_M 32
 
-enum { ORC_SYS_POS_ORN = 0, ORC_SYS_POS_ORN_TIME = 1 };
+enum { ORC_SYS_POS_ORN = 0, ORC_SYS_POS_ORN_TIME = 1, ORC_SYS_JOINT = 2 /* JointSpacePlannerSys, nb_deriv = 1 (App. D-10: 2 is broken upstream) */ };
 
 /* URDF chain base->tip, as orocos_kdl sees it after TinyURDFParser: one segment per URDF joint,
  * T_seg(q) = Trans(xyz) * R_fixed * Rot(axis, q)  (fixed joints: no Rot), then the user tool frame
@@ -62,6 +62,7 @@ typedef struct {
      * SequentialSystem.cpp:144-150 -> System.cpp:221); 0 = the system's R_diag */
     int has_Ru;
     double Ru[ORC_MAX_NU];
+    double jt[ORC_MAX_NX];      /* AngularKeypoint target (joint space, AngularKeypoint.cpp:15-27) */
 } orc_keypoint;
 
 typedef struct {

