@@ -541,7 +541,11 @@ Mat System::getQMatrix(bool sparse) {  // System.cpp:341-361
 
 void System::lower(ilqr_problem_desc* d) const {
     ilqr_desc_defaults(d);
-    if (!r->lowerChain(d)) throw std::runtime_error("[ilqr_hip] this SimulationInterface cannot be lowered to the device (only sim::KDLRobot chains can)");
+    if (!r->lowerChain(d)) {
+        if (kind_ != ILQR_SYS_JOINT) throw std::runtime_error("[ilqr_hip] this SimulationInterface cannot be lowered to the device (only sim::KDLRobot chains can)");
+        d->dof = r->getDOF();  // joint-space systems need no kinematic chain
+        d->n_seg = 0;
+    }
     d->kind = kind_;
     d->nb_deriv = nb_deriv_;
     d->horizon = horizon_;
@@ -692,6 +696,53 @@ Vec PosOrnPlannerSys::getState() {
     return xk;
 }
 void PosOrnPlannerSys::reset() { r->setConfiguration(q0_, dq0_); }
+
+// ---- AngularKeypoint (AngularKeypoint.cpp:15-27), JointSpacePlannerSys (JointSpacePlannerSys.cpp:50-122)
+Vec AngularKeypoint::getState() const {
+    Vec st = position_;
+    if (type_ == SECOND_ORDER) st.insert(st.end(), dposition_.begin(), dposition_.end());
+    return st;
+}
+Vec AngularKeypoint::diff(const Vec& state) const {
+    const Vec tg = getState();
+    if (state.size() != tg.size()) throw std::runtime_error("[AngularKeypoint] state size mismatch");
+    Vec r(tg.size());
+    for (size_t i = 0; i < tg.size(); i++) r[i] = tg[i] - state[i];
+    return r;
+}
+JointSpacePlannerSys::JointSpacePlannerSys(const std::shared_ptr<sim::SimulationInterface>& r, const std::vector<std::shared_ptr<Keypoint>>& kps, const Vec& Rt,
+                                           const Vec& qMax, const Vec& qMin, const Vec& dqMax, const Vec& dqMin, int horizon, int nb_deriv, double dt)
+    : System(r, kps, Rt, qMax, qMin, dqMax, dqMin, horizon, nb_deriv, {"JNT"}) { localInit(dt); }
+JointSpacePlannerSys::JointSpacePlannerSys(const std::shared_ptr<sim::SimulationInterface>& r, const std::vector<std::shared_ptr<Keypoint>>& kps, const Vec& Rt,
+                                           const Vec& qMax, const Vec& qMin, int horizon, int nb_deriv, double dt)
+    : System(r, kps, Rt, qMax, qMin, Vec(), Vec(), horizon, nb_deriv, {"JNT"}) { localInit(dt); }
+JointSpacePlannerSys::JointSpacePlannerSys(const std::shared_ptr<sim::SimulationInterface>& r, const std::vector<std::shared_ptr<Keypoint>>& kps, const Vec& Rt,
+                                           int horizon, int nb_deriv, double dt)
+    : System(r, kps, Rt, horizon, nb_deriv, {"JNT"}) { localInit(dt); }
+void JointSpacePlannerSys::localInit(double dt) {  // :54-75
+    kind_ = ILQR_SYS_JOINT;
+    dt_ = dt;
+    q0_ = r->getJointsPos();
+    dq0_ = r->getJointsVel();
+    x0_ = q0_;
+    if (nb_deriv_ != 1) append(x0_, dq0_);
+    f_x0_ = x0_;
+    nb_state_var_ = (int)x0_.size();
+    nb_ctrl_var_ = r->getDOF();
+    nb_target_var_ = (int)f_x0_.size();
+    nb_Q_var_ = nb_target_var_;
+}
+Vec JointSpacePlannerSys::getState() {
+    Vec xk = r->getJointsPos();
+    if (nb_deriv_ != 1) append(xk, r->getJointsVel());
+    return xk;
+}
+void JointSpacePlannerSys::reset() { r->setConfiguration(q0_, dq0_); }
+void JointSpacePlannerSys::lower(ilqr_problem_desc* d) const {
+    if (nb_deriv_ != 1) throw std::runtime_error("[ilqr_hip] JointSpacePlannerSys is lowered for nbDeriv = 1 only (the 2nd-order variant is inconsistent upstream)");
+    if (r->getDOF() != 7) throw std::runtime_error("[ilqr_hip] joint-space systems are lowered for 7 joints (pad smaller robots: zero precision, zero limit weight)");
+    System::lower(d);  // f(x) = x needs no chain, but a KDLRobot's chain is kept for ilqr_fk_batch users
+}
 
 PosOrnTimePlannerSys::PosOrnTimePlannerSys(const std::shared_ptr<sim::SimulationInterface>& r, const std::vector<std::shared_ptr<Keypoint>>& kps, const Vec& Rt,
                                            const Vec& qMax, const Vec& qMin, const Vec& dqMax, const Vec& dqMin, int horizon, int nb_deriv)

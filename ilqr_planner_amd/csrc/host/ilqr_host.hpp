@@ -185,6 +185,23 @@ protected:
     Vec orn_thresh_;
 };
 
+class AngularKeypoint : public Keypoint {  // AngularKeypoint.h:15-45: joint-space target, residual = target - state
+public:
+    AngularKeypoint(const Vec& position, const Mat& precision, const int& timestep)
+        : Keypoint(timestep, FIRST_ORDER, "JNT"), position_(position), precision_(precision) {}
+    AngularKeypoint(const Vec& position, const Vec& dposition, const Mat& precision, const int& timestep)
+        : Keypoint(timestep, SECOND_ORDER, "JNT"), position_(position), dposition_(dposition), precision_(precision) {}
+    Vec getPosition() const { return position_; }
+    Mat getPrecision() const override { return precision_; }
+    Vec diff(const Vec& state) const override;
+    Vec getState() const override;
+    Vec targetFx() const override { return getState(); }
+
+protected:
+    Vec position_, dposition_;
+    Mat precision_;
+};
+
 class SpacetimeKeypoint : public PosOrnKeypoint {  // SpacetimeKeypoint.h:15-45
 public:
     SpacetimeKeypoint(const Vec& position, const Vec& orientation, const Mat& precision, const double& continuous_time, const int& timestep);
@@ -257,6 +274,24 @@ public:
                      int horizon, int nb_deriv, double dt);
     Vec getState() override;
     void reset() override;
+
+protected:
+    void localInit(double dt);
+};
+
+// Target space = joint space, J = I (JointSpacePlannerSys.h / .cpp:50-122).  Device path: nb_deriv = 1 and the 7 joints the
+// kernels are built for (the reference's 2nd-order variant is dimensionally inconsistent).
+class JointSpacePlannerSys : public System {
+public:
+    JointSpacePlannerSys(const std::shared_ptr<sim::SimulationInterface>& r, const std::vector<std::shared_ptr<Keypoint>>& keypoints, const Vec& RtDiag,
+                         const Vec& qMax, const Vec& qMin, const Vec& dqMax, const Vec& dqMin, int horizon, int nb_deriv, double dt);
+    JointSpacePlannerSys(const std::shared_ptr<sim::SimulationInterface>& r, const std::vector<std::shared_ptr<Keypoint>>& keypoints, const Vec& RtDiag,
+                         const Vec& qMax, const Vec& qMin, int horizon, int nb_deriv, double dt);
+    JointSpacePlannerSys(const std::shared_ptr<sim::SimulationInterface>& r, const std::vector<std::shared_ptr<Keypoint>>& keypoints, const Vec& RtDiag,
+                         int horizon, int nb_deriv, double dt);
+    Vec getState() override;
+    void reset() override;
+    void lower(ilqr_problem_desc* d) const override;
 
 protected:
     void localInit(double dt);

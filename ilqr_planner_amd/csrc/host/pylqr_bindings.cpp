@@ -150,6 +150,11 @@ PYBIND11_MODULE(PyLQR, m) {
              py::arg("pos_thresh"), py::arg("orn_thresh"), py::arg("timestep"))
         .def(py::init<const Vec&, const Vec&, const Vec&, const Vec&, const Mat&, const double&, const Vec&, const int&>(), py::arg("position"), py::arg("dposition"),
              py::arg("orientation"), py::arg("dorientation"), py::arg("precision"), py::arg("pos_thresh"), py::arg("orn_thresh"), py::arg("timestep"));
+    // bindings.cpp:368-371
+    py::class_<sys::AngularKeypoint, sys::Keypoint, std::shared_ptr<sys::AngularKeypoint>>(m_sys, "AngularKeypoint")
+        .def(py::init<const Vec&, const Mat&, const int&>(), py::arg("position"), py::arg("precision"), py::arg("timestep"))
+        .def(py::init<const Vec&, const Vec&, const Mat&, const int&>(), py::arg("position"), py::arg("dposition"), py::arg("precision"), py::arg("timestep"))
+        .def("get_position", &sys::AngularKeypoint::getPosition);
     py::class_<sys::SpacetimeKeypoint, sys::PosOrnKeypoint, std::shared_ptr<sys::SpacetimeKeypoint>>(m_sys, "SpacetimeKeypoint")
         .def(py::init<const Vec&, const Vec&, const Mat&, const double&, const int&>(), py::arg("position"), py::arg("orientation"), py::arg("precision"),
              py::arg("continuous_time"), py::arg("timestep"))
@@ -176,6 +181,14 @@ PYBIND11_MODULE(PyLQR, m) {
              py::arg("qMax"), py::arg("qMin"), py::arg("horizon"), py::arg("nbDeriv"), py::arg("dt"))
         .def(py::init<const SimP&, const KPs&, const Vec&, int, int, double>(), py::arg("r"), py::arg("keypoints"), py::arg("RtDiag"), py::arg("horizon"),
              py::arg("nbDeriv"), py::arg("dt"));
+    // bindings.cpp:528-536
+    py::class_<sys::JointSpacePlannerSys, sys::System, std::shared_ptr<sys::JointSpacePlannerSys>>(m_sys, "JointSpacePlannerSys")
+        .def(py::init<const SimP&, const KPs&, const Vec&, const Vec&, const Vec&, const Vec&, const Vec&, int, int, double>(), py::arg("r"), py::arg("keypoints"),
+             py::arg("RtDiag"), py::arg("qMax"), py::arg("qMin"), py::arg("dqMax"), py::arg("dqMin"), py::arg("horizon"), py::arg("nbDeriv"), py::arg("dt"))
+        .def(py::init<const SimP&, const KPs&, const Vec&, const Vec&, const Vec&, int, int, double>(), py::arg("r"), py::arg("keypoints"), py::arg("RtDiag"),
+             py::arg("qMax"), py::arg("qMin"), py::arg("horizon"), py::arg("nbDeriv"), py::arg("dt"))
+        .def(py::init<const SimP&, const KPs&, const Vec&, int, int, double>(), py::arg("r"), py::arg("keypoints"), py::arg("RtDiag"), py::arg("horizon"), py::arg("nbDeriv"),
+             py::arg("dt"));
     py::class_<sys::PosOrnTimePlannerSys, sys::System, std::shared_ptr<sys::PosOrnTimePlannerSys>>(m_sys, "PosOrnTimePlannerSys")
         .def(py::init<const SimP&, const KPs&, const Vec&, const Vec&, const Vec&, const Vec&, const Vec&, int, int>(), py::arg("r"), py::arg("keypoints"),
              py::arg("RtDiag"), py::arg("qMax"), py::arg("qMin"), py::arg("dqMax"), py::arg("dqMin"), py::arg("horizon"), py::arg("nbDeriv"))

@@ -248,3 +248,44 @@ def test_multi_sys_tutorial(capsys):
     np.testing.assert_allclose(tr2.get_ee_pos(), k2_["pos"], atol=5e-3)
     with pytest.raises(RuntimeError):  # SequentialSystem.cpp:36-56
         SequentialSystem(rbt, [sys1, PosOrnPlannerSys(tr2, [], cmd_penalties, qMax, -qMax, dqMax, -dqMax, horizon + 1, 1, dt)], cmd_penalties, horizon, 1)
+
+
+def test_joint_space_tutorial(capsys):
+    """JOINT_SPACE_SYS.ipynb (cells 4-15) with seeded targets (the notebook draws them unseeded, so its numbers cannot be pinned):
+    the problem is linear-quadratic, so ILQRRecursive reaches the optimum in one iteration and then fails to improve -- the
+    shape of the stored trace (alpha 1, then 0.000976562) -- and Batch-CP converges in a few steps."""
+    from PyLQR.sim import KDLRobot
+    from PyLQR.solver import BatchILQRCP, ILQRRecursive
+    from PyLQR.system import AngularKeypoint, JointSpacePlannerSys
+    from PyLQR.utils import PythonCallbackMessage, primitives
+
+    dof, nb_ctrl_var, horizon, dt = 7, 7, 100, 0.1
+    q0 = golden()["cases"]["POS_ORN_SYS"]["problem"]["q0"]
+    dq0 = [0] * dof
+    qMax = np.array([2.8973, 1.7628, 2.8973, -0.0698, 2.8973, 3.7525, 2.8973])
+    qMin = np.array([-2.8973, -1.7628, -2.8973, -3.0718, -2.8973, -0.0175, -2.8973])
+    rbt = KDLRobot(URDF, "panda_link0", "panda_tip", q0, dq0)
+    rng = np.random.default_rng(5)
+    target_1, target_2 = rng.uniform(qMin, qMax), rng.uniform(qMin, qMax)
+    kp1, kp2 = AngularKeypoint(target_1, np.identity(dof), horizon // 2 - 1), AngularKeypoint(target_2, np.identity(dof), horizon - 1)
+    np.testing.assert_allclose(kp1.diff(np.asarray(q0)), target_1 - np.asarray(q0))
+    sys_ = JointSpacePlannerSys(rbt, [kp1, kp2], [1e-5] * nb_ctrl_var, qMax, qMin, horizon, 1, dt)
+    assert (sys_.get_nb_state_var(), sys_.get_nb_ctrl_var(), sys_.get_nb_target_var()) == (7, 7, 7)
+    u0 = np.tile(np.array([0] * nb_ctrl_var), horizon - 1)
+    PSI = np.kron(primitives.build_psi_unitstep(horizon - 1, 2), np.identity(nb_ctrl_var))
+    cb = PythonCallbackMessage()
+    capsys.readouterr()
+    X2, F_X2, U2, K2, k2, cost = ILQRRecursive(sys_).solve(u0.reshape((-1, nb_ctrl_var)), 10, True, True, cb)
+    lines = capsys.readouterr().out.strip().splitlines()
+    assert len(lines) == 2 and "alpha= 1" in lines[0] and "alpha= 0.000976562" in lines[1], lines
+    X2 = np.asarray(X2)
+    np.testing.assert_allclose(X2[horizon // 2 - 1], target_1, atol=5e-3)
+    np.testing.assert_allclose(X2[horizon - 1], target_2, atol=5e-3)
+    np.testing.assert_allclose(np.asarray(F_X2), X2)  # target space = state space
+    U1 = BatchILQRCP(sys_, PSI).solve(10, u0, True, cb)
+    lines = capsys.readouterr().out.strip().splitlines()
+    assert 2 <= len(lines) <= 6 and float(LINE.match(lines[-1]).group(2)) < float(LINE.match(lines[0]).group(2)) * 1e-2, lines
+    rbt.set_conf(q0, dq0, True)
+    for u in np.asarray(U1).reshape((horizon - 1, nb_ctrl_var)):
+        rbt.send_vel(dt, u, True)
+    np.testing.assert_allclose(rbt.get_q(), target_2, atol=5e-2)
