@@ -542,7 +542,9 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
                 else launch_forward_rows(nd, KER_FWD_APPLY, p->bufs, p->B, c->stream, f);
             } else if (line_search) {
                 ProfScope ps(c, ILQR_PROF_APPLY);
-                launch_solver_v2(kind, nd, KER_FWD_APPLY, al, p->bufs, p->B, p->T, c->stream, f);
+                static const bool tile_apply = std::getenv("ILQR_APPLY") && !std::strcmp(std::getenv("ILQR_APPLY"), "tile");
+                if (kind == 1 && !tile_apply) launch_apply_rows_tm(nd, p->bufs, p->B, c->stream, f);  // 8 lanes per instance
+                else launch_solver_v2(kind, nd, KER_FWD_APPLY, al, p->bufs, p->B, p->T, c->stream, f);
             }
             if (al && !fwd_wave) {  // active-set weights of the accepted trajectory (+ multiplier update every `lag` iterations)
                 ProfScope ps(c, ILQR_PROF_OTHER);

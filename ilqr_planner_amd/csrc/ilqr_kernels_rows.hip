@@ -527,6 +527,117 @@ __global__ void k_flip(Bufs a) {
     }
 }
 
+// Re-roll of the accepted step size for the TIME systems (dt = u_last^2: the closed loop is not linear in alpha, so the winner of
+// k_forward_tile's alpha-parallel pass has to be rolled out again when it was not the speculated one).  k_forward_tile<APPLY>
+// does it with one lane in sixteen; here 8 lanes share an instance: lane r owns control row r and the joint state (q_r, dq_r),
+// lane 7 the time control and the time state.  Per step: LDS all-gather of dx (n_x values), 16-term dot product with the lane's
+// gain row (register ring, 16-byte loads), dt = s^2 broadcast from lane 7, dynamics local to the lane.
+template <class S>
+__global__ __launch_bounds__(64) void k_apply_rows_tm(Bufs a, FwdArgs f) {
+    static_assert(S::TM == 1, "time systems");
+    constexpr int NX = S::NX, NU = S::NU, ND = S::ND;
+    static_assert(NU == 8, "one control row per lane of an 8-lane group");
+    constexpr int ROWP = kd_rowp(NX), RS = NU * ROWP;
+    constexpr int DXS = ROWP + 2;   // per-instance stride of the dx image (+16 B bank spread)
+    constexpr int NLD = ROWP + ND + 1;
+    constexpr int PF = 3;
+    __shared__ __attribute__((aligned(16))) double sDX[8 * DXS];
+    __shared__ double sS[8][2];     // per instance: the time control of the step
+
+    const DevDesc& d = *a.desc;
+    const int lane = threadIdx.x, g = lane >> 3, r = lane & 7;
+    const int b = xcd_tile() * 8 + g;
+    const int Bp = d.Bp, T = d.T, B = d.B;
+    const bool inst_ok = (b < B) && (a.pend[b < B ? b : 0] > 0);
+    if (__ballot(inst_ok ? 1 : 0) == 0ull) return;  // wave-uniform
+    const int bb = (b < B) ? b : 0;
+    const bool isT = (r == DOF);    // lane 7: time control / time state
+    const int rj = isT ? 0 : r;     // joint index for the state rows of this lane (clamped for lane 7)
+    const double alpha = ldexp(1.0, -((inst_ok ? a.pend[bb] : 1) - 1));
+    const int cur = a.cur[bb];
+    const double* pK = a.KD + (size_t)bb * RS + r * ROWP;
+    const double* pXq = a.X[cur] + (size_t)(isT ? NX - 1 : rj) * Bp + bb;            // q_r, or t for lane 7
+    const double* pXd = a.X[cur] + (size_t)(ND == 2 ? DOF + rj : rj) * Bp + bb;      // dq_r (2nd order)
+    const double* pU = a.U[cur] + (size_t)r * Bp + bb;
+    const size_t sK_ = (size_t)Bp * RS, sU_ = (size_t)NU * Bp, sX_ = (size_t)NX * Bp;
+    double* oXq = a.X[1 - cur] + (size_t)(isT ? NX - 1 : rj) * Bp + bb;
+    double* oXd = a.X[1 - cur] + (size_t)(ND == 2 ? DOF + rj : rj) * Bp + bb;
+    double* oU = a.U[1 - cur] + (size_t)r * Bp + bb;
+
+    double ring[PF][NLD];
+    auto fetch = [&](int slot, int k) {  // unconditional; the pointers stop at the last timestep
+        UNR for (int q = 0; q < ROWP / 2; q++) {
+            const double2 v2 = reinterpret_cast<const double2*>(pK)[q];
+            ring[slot][2 * q] = v2.x;
+            ring[slot][2 * q + 1] = v2.y;
+        }
+        ring[slot][ROWP] = *pXq;
+        if (ND == 2) ring[slot][ROWP + 1] = *pXd;
+        ring[slot][ROWP + ND] = *pU;
+        const size_t adv = (k < T - 2) ? 1 : 0;  // uniform
+        pK += adv * sK_; pXq += adv * sX_; pXd += adv * sX_; pU += adv * sU_;
+    };
+    UNR for (int q = 0; q < PF; q++) { fetch(q, q); __builtin_amdgcn_sched_barrier(0); }
+
+    // state of this lane: joint r (q, dq) or, lane 7, the time
+    double xq = isT ? 0.0 : AT(a.q0, rj, bb);
+    double xd = (ND == 2 && !isT) ? AT(a.dq0, rj, bb) : 0.0;
+    double* myDX = sDX + g * DXS;
+
+    const int nsteps = T - 1;
+    for (int k0 = 0; k0 < nsteps; k0 += PF) {
+        UNR for (int jj = 0; jj < PF; jj++) {
+            const int k = k0 + jj;
+            double Kr[NX];
+            UNR for (int jx = 0; jx < NX; jx++) Kr[jx] = ring[jj][jx];
+            const double dr = ring[jj][NX], xbq = ring[jj][ROWP], xbd = (ND == 2) ? ring[jj][ROWP + 1] : 0.0, ub = ring[jj][ROWP + ND];
+            fetch(jj, k + PF);
+            if (k >= nsteps) continue;  // uniform; dummy step of the last group
+            // ---- all-gather of dx = x - xbar (state order [q(7) | dq(7) | t])
+            if (isT) myDX[NX - 1] = xq - xbq;
+            else {
+                myDX[rj] = xq - xbq;
+                if (ND == 2) myDX[DOF + rj] = xd - xbd;
+            }
+            LDS_ORDER();
+            double s0 = 0, s1 = 0;
+            UNR for (int jx = 0; jx < NX; jx += 2) s0 += Kr[jx] * myDX[jx];
+            UNR for (int jx = 1; jx < NX; jx += 2) s1 += Kr[jx] * myDX[jx];
+            const double du = (s0 + s1) + alpha * dr;
+            const double u = ub + du;
+            if (isT) sS[g][0] = u;
+            LDS_ORDER();
+            const double dts = sS[g][0];
+            const double dt = dts * dts;
+            if (inst_ok) {
+                *oXq = xq;
+                if (ND == 2 && !isT) *oXd = xd;
+                *oU = u;
+            }
+            oXq += sX_; oXd += sX_; oU += sU_;
+            // ---- dynamics (SimulationInterface.cpp:19-31 with dt = u_last^2, PosOrnTimePlannerSys.cpp:149-184), local to the lane
+            if (isT) {
+                xq = xq + dt;
+            } else if (ND == 1) {
+                xq = xq + (dt * u + dt * dt / 2 * 0.0);
+            } else {
+                const double vv = xd;
+                xq = xq + (dt * vv + dt * dt / 2 * u);
+                xd = vv + dt * u;
+            }
+            LDS_ORDER();
+        }
+    }
+    if (inst_ok) {  // x_{T-1}
+        *oXq = xq;
+        if (ND == 2 && !isT) *oXd = xd;
+    }
+    if (inst_ok && r == 0) {  // the early stop was decided by k_select_x
+        a.cur[bb] = 1 - cur;
+        a.pend[bb] = 0;
+    }
+}
+
 template <class S>
 static void launch_lin_sys(const Bufs& a, int B, int T, hipStream_t st, const FwdArgs& f, int which) {
     if (which == KER_FWD_SPEC) {
@@ -557,6 +668,12 @@ static void launch_rows_sys(int which, const Bufs& a, int B, hipStream_t st, con
     } else {
         hipLaunchKernelGGL((k_forward_rows<S, 16, false>), grid, block, 0, st, a, f);
     }
+}
+
+void launch_apply_rows_tm(int nd, const Bufs& a, int B, hipStream_t st, const FwdArgs& f) {
+    const dim3 grid(grid_x8((B + 7) / 8)), block(64);
+    if (nd == 1) hipLaunchKernelGGL((k_apply_rows_tm<Sys<1, 1>>), grid, block, 0, st, a, f);
+    else hipLaunchKernelGGL((k_apply_rows_tm<Sys<1, 2>>), grid, block, 0, st, a, f);
 }
 
 bool forward_rows_supported(int kind, int nd, int n_alpha) { return kind == 0 && (nd == 1 || nd == 2) && n_alpha <= 16; }
