@@ -493,7 +493,6 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
     FwdArgs f;
     std::memset(&f, 0, sizeof(f));
     f.line_search = line_search; f.early_stop = early_stop; f.nb_iter = nb_iter; f.penalty_roll = penalty; f.n_alpha = n_alpha; f.al = al ? 1 : 0; f.n_kp = p->desc.n_kp;
-    f.dbg = std::getenv("ILQR_DBG") ? std::atoi(std::getenv("ILQR_DBG")) : 0;
     for (int k = 0; k < p->desc.n_kp; k++) f.kp_ext |= p->desc.kp_dist[k] | p->desc.kp_has_frame[k] | p->desc.kp_has_Ru[k];
     {
         ProfScope ps(c, ILQR_PROF_ROLLOUT);

@@ -51,7 +51,6 @@ struct FwdArgs {
     int al;       // 1 = AL_ILQR semantics (early stop without the cost test)
     int n_alpha;  // number of step sizes 1, 1/2, ... the line search may try (11 for alpha_floor = 1e-3)
     double penalty_roll, penalty_update;
-    int dbg;      // experiment switches (ILQR_DBG), 0 in production
     int kp_ext;   // some keypoint has a dead zone, an object frame or its own control penalty (selects the full keypoint code)
 };
 
