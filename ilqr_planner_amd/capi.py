@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libilqr_hip.so")
 
 MAX_SEG, MAX_KP, MAX_NX, MAX_NU, MAX_NF, MAX_NQ = 24, 8, 15, 8, 15, 13
-SYS_POS_ORN, SYS_POS_ORN_TIME, SYS_JOINT = 0, 1, 2
+SYS_POS_ORN, SYS_POS_ORN_TIME, SYS_JOINT, SYS_JOINT_TIME = 0, 1, 2, 3
 STATUS_OK, STATUS_NONFINITE, STATUS_ALPHA_FLOOR = 0, 1, 2
 PROF_ROLLOUT, PROF_BACKWARD, PROF_FORWARD, PROF_OTHER, PROF_APPLY = 0, 1, 2, 3, 4
 

@@ -542,7 +542,7 @@ Mat System::getQMatrix(bool sparse) {  // System.cpp:341-361
 void System::lower(ilqr_problem_desc* d) const {
     ilqr_desc_defaults(d);
     if (!r->lowerChain(d)) {
-        if (kind_ != ILQR_SYS_JOINT) throw std::runtime_error("[ilqr_hip] this SimulationInterface cannot be lowered to the device (only sim::KDLRobot chains can)");
+        if (kind_ != ILQR_SYS_JOINT && kind_ != ILQR_SYS_JOINT_TIME) throw std::runtime_error("[ilqr_hip] this SimulationInterface cannot be lowered to the device (only sim::KDLRobot chains can)");
         d->dof = r->getDOF();  // joint-space systems need no kinematic chain
         d->n_seg = 0;
     }
@@ -704,7 +704,7 @@ Vec AngularKeypoint::getState() const {
     return st;
 }
 Vec AngularKeypoint::diff(const Vec& state) const {
-    const Vec tg = getState();
+    const Vec tg = AngularKeypoint::getState();  // qualified as in AngularKeypoint.cpp:25 (AngularTimeKeypoint appends the time itself)
     if (state.size() != tg.size()) throw std::runtime_error("[AngularKeypoint] state size mismatch");
     Vec r(tg.size());
     for (size_t i = 0; i < tg.size(); i++) r[i] = tg[i] - state[i];
@@ -742,6 +742,57 @@ void JointSpacePlannerSys::lower(ilqr_problem_desc* d) const {
     if (nb_deriv_ != 1) throw std::runtime_error("[ilqr_hip] JointSpacePlannerSys is lowered for nbDeriv = 1 only (the 2nd-order variant is inconsistent upstream)");
     if (r->getDOF() != 7) throw std::runtime_error("[ilqr_hip] joint-space systems are lowered for 7 joints (pad smaller robots: zero precision, zero limit weight)");
     System::lower(d);  // f(x) = x needs no chain, but a KDLRobot's chain is kept for ilqr_fk_batch users
+}
+
+// ---- AngularTimeKeypoint (AngularTimeKeypoint.cpp:15-30), JointSpaceTimePlannerSys (JointSpaceTimePlannerSys.cpp:50-160)
+Vec AngularTimeKeypoint::getState() const {
+    Vec st = AngularKeypoint::getState();
+    st.push_back(continuous_time_);
+    return st;
+}
+Vec AngularTimeKeypoint::diff(const Vec& state) const {
+    if (state.empty()) throw std::runtime_error("[AngularTimeKeypoint] empty state");
+    Vec r = AngularKeypoint::diff(Vec(state.begin(), state.end() - 1));
+    r.push_back(continuous_time_ - state.back());
+    return r;
+}
+JointSpaceTimePlannerSys::JointSpaceTimePlannerSys(const std::shared_ptr<sim::SimulationInterface>& r, const std::vector<std::shared_ptr<Keypoint>>& kps,
+                                                   const Vec& Rt, const Vec& qMax, const Vec& qMin, const Vec& dqMax, const Vec& dqMin, int horizon, int nb_deriv)
+    : System(r, kps, Rt, qMax, qMin, dqMax, dqMin, horizon, nb_deriv, {"JNT_TIME"}) { localInit(); }
+JointSpaceTimePlannerSys::JointSpaceTimePlannerSys(const std::shared_ptr<sim::SimulationInterface>& r, const std::vector<std::shared_ptr<Keypoint>>& kps,
+                                                   const Vec& Rt, const Vec& qMax, const Vec& qMin, int horizon, int nb_deriv)
+    : System(r, kps, Rt, qMax, qMin, Vec(), Vec(), horizon, nb_deriv, {"JNT_TIME"}) { localInit(); }
+JointSpaceTimePlannerSys::JointSpaceTimePlannerSys(const std::shared_ptr<sim::SimulationInterface>& r, const std::vector<std::shared_ptr<Keypoint>>& kps,
+                                                   const Vec& Rt, int horizon, int nb_deriv)
+    : System(r, kps, Rt, horizon, nb_deriv, {"JNT_TIME"}) { localInit(); }
+void JointSpaceTimePlannerSys::localInit() {  // :50-78
+    kind_ = ILQR_SYS_JOINT_TIME;
+    dt_ = 0;
+    q0_ = r->getJointsPos();
+    dq0_ = r->getJointsVel();
+    x0_ = q0_;
+    if (nb_deriv_ != 1) append(x0_, dq0_);
+    x0_.push_back(0);
+    f_x0_ = x0_;
+    nb_state_var_ = (int)x0_.size();
+    nb_ctrl_var_ = r->getDOF() + 1;
+    nb_target_var_ = (int)f_x0_.size();
+    nb_Q_var_ = nb_target_var_;
+    state_max_.push_back(0);  // the time state is never limited (weight 0)
+    state_min_.push_back(0);
+    joint_limits_weight_.push_back(0);
+}
+Vec JointSpaceTimePlannerSys::getState() {
+    Vec xk = r->getJointsPos();
+    if (nb_deriv_ != 1) append(xk, r->getJointsVel());
+    xk.push_back(r->getTime());
+    return xk;
+}
+void JointSpaceTimePlannerSys::reset() { r->setConfiguration(q0_, dq0_); }
+void JointSpaceTimePlannerSys::lower(ilqr_problem_desc* d) const {
+    if (nb_deriv_ != 1) throw std::runtime_error("[ilqr_hip] JointSpaceTimePlannerSys is lowered for nbDeriv = 1 only");
+    if (r->getDOF() != 7) throw std::runtime_error("[ilqr_hip] joint-space systems are lowered for 7 joints");
+    System::lower(d);
 }
 
 PosOrnTimePlannerSys::PosOrnTimePlannerSys(const std::shared_ptr<sim::SimulationInterface>& r, const std::vector<std::shared_ptr<Keypoint>>& kps, const Vec& Rt,

@@ -202,6 +202,20 @@ protected:
     Mat precision_;
 };
 
+class AngularTimeKeypoint : public AngularKeypoint {  // AngularTimeKeypoint.h: joint target + continuous time
+public:
+    AngularTimeKeypoint(const Vec& position, const Mat& precision, const double& continuous_time, const int& timestep)
+        : AngularKeypoint(position, precision, timestep), continuous_time_(continuous_time) { TAG_ = "JNT_TIME"; }
+    AngularTimeKeypoint(const Vec& position, const Vec& dposition, const Mat& precision, const double& continuous_time, const int& timestep)
+        : AngularKeypoint(position, dposition, precision, timestep), continuous_time_(continuous_time) { TAG_ = "JNT_TIME"; }
+    double getContinuousTime() { return continuous_time_; }
+    Vec diff(const Vec& state) const override;
+    Vec getState() const override;
+
+protected:
+    double continuous_time_;
+};
+
 class SpacetimeKeypoint : public PosOrnKeypoint {  // SpacetimeKeypoint.h:15-45
 public:
     SpacetimeKeypoint(const Vec& position, const Vec& orientation, const Mat& precision, const double& continuous_time, const int& timestep);
@@ -295,6 +309,23 @@ public:
 
 protected:
     void localInit(double dt);
+};
+
+// JointSpacePlannerSys with a time state and dt = u_last^2 (JointSpaceTimePlannerSys.h / .cpp:50-160); nb_deriv = 1, 7 joints on the device
+class JointSpaceTimePlannerSys : public System {
+public:
+    JointSpaceTimePlannerSys(const std::shared_ptr<sim::SimulationInterface>& r, const std::vector<std::shared_ptr<Keypoint>>& keypoints, const Vec& RtDiag,
+                             const Vec& qMax, const Vec& qMin, const Vec& dqMax, const Vec& dqMin, int horizon, int nb_deriv);
+    JointSpaceTimePlannerSys(const std::shared_ptr<sim::SimulationInterface>& r, const std::vector<std::shared_ptr<Keypoint>>& keypoints, const Vec& RtDiag,
+                             const Vec& qMax, const Vec& qMin, int horizon, int nb_deriv);
+    JointSpaceTimePlannerSys(const std::shared_ptr<sim::SimulationInterface>& r, const std::vector<std::shared_ptr<Keypoint>>& keypoints, const Vec& RtDiag,
+                             int horizon, int nb_deriv);
+    Vec getState() override;
+    void reset() override;
+    void lower(ilqr_problem_desc* d) const override;
+
+protected:
+    void localInit();
 };
 
 class PosOrnTimePlannerSys : public System {  // PosOrnTimePlannerSys.h

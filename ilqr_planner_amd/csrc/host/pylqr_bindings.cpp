@@ -155,6 +155,12 @@ PYBIND11_MODULE(PyLQR, m) {
         .def(py::init<const Vec&, const Mat&, const int&>(), py::arg("position"), py::arg("precision"), py::arg("timestep"))
         .def(py::init<const Vec&, const Vec&, const Mat&, const int&>(), py::arg("position"), py::arg("dposition"), py::arg("precision"), py::arg("timestep"))
         .def("get_position", &sys::AngularKeypoint::getPosition);
+    // bindings.cpp:388-392
+    py::class_<sys::AngularTimeKeypoint, sys::AngularKeypoint, std::shared_ptr<sys::AngularTimeKeypoint>>(m_sys, "AngularTimeKeypoint")
+        .def(py::init<const Vec&, const Mat&, const double&, const int&>(), py::arg("position"), py::arg("precision"), py::arg("continuous_time"), py::arg("timestep"))
+        .def(py::init<const Vec&, const Vec&, const Mat&, const double&, const int&>(), py::arg("position"), py::arg("dposition"), py::arg("precision"),
+             py::arg("continuous_time"), py::arg("timestep"))
+        .def("get_continuous_time", &sys::AngularTimeKeypoint::getContinuousTime);
     py::class_<sys::SpacetimeKeypoint, sys::PosOrnKeypoint, std::shared_ptr<sys::SpacetimeKeypoint>>(m_sys, "SpacetimeKeypoint")
         .def(py::init<const Vec&, const Vec&, const Mat&, const double&, const int&>(), py::arg("position"), py::arg("orientation"), py::arg("precision"),
              py::arg("continuous_time"), py::arg("timestep"))
@@ -189,6 +195,13 @@ PYBIND11_MODULE(PyLQR, m) {
              py::arg("qMax"), py::arg("qMin"), py::arg("horizon"), py::arg("nbDeriv"), py::arg("dt"))
         .def(py::init<const SimP&, const KPs&, const Vec&, int, int, double>(), py::arg("r"), py::arg("keypoints"), py::arg("RtDiag"), py::arg("horizon"), py::arg("nbDeriv"),
              py::arg("dt"));
+    // bindings.cpp:571-579
+    py::class_<sys::JointSpaceTimePlannerSys, sys::System, std::shared_ptr<sys::JointSpaceTimePlannerSys>>(m_sys, "JointSpaceTimePlannerSys")
+        .def(py::init<const SimP&, const KPs&, const Vec&, const Vec&, const Vec&, const Vec&, const Vec&, int, int>(), py::arg("r"), py::arg("keypoints"),
+             py::arg("RtDiag"), py::arg("qMax"), py::arg("qMin"), py::arg("dqMax"), py::arg("dqMin"), py::arg("horizon"), py::arg("nbDeriv"))
+        .def(py::init<const SimP&, const KPs&, const Vec&, const Vec&, const Vec&, int, int>(), py::arg("r"), py::arg("keypoints"), py::arg("RtDiag"),
+             py::arg("qMax"), py::arg("qMin"), py::arg("horizon"), py::arg("nbDeriv"))
+        .def(py::init<const SimP&, const KPs&, const Vec&, int, int>(), py::arg("r"), py::arg("keypoints"), py::arg("RtDiag"), py::arg("horizon"), py::arg("nbDeriv"));
     py::class_<sys::PosOrnTimePlannerSys, sys::System, std::shared_ptr<sys::PosOrnTimePlannerSys>>(m_sys, "PosOrnTimePlannerSys")
         .def(py::init<const SimP&, const KPs&, const Vec&, const Vec&, const Vec&, const Vec&, const Vec&, int, int>(), py::arg("r"), py::arg("keypoints"),
              py::arg("RtDiag"), py::arg("qMax"), py::arg("qMin"), py::arg("dqMax"), py::arg("dqMin"), py::arg("horizon"), py::arg("nbDeriv"))

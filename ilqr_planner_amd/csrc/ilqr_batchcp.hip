@@ -637,6 +637,7 @@ int batchcp_solve(BatchCPState& st, const DevDesc& h, Bufs& bufs, int nx, int nu
         return 1;
     }
     static const bool general = std::getenv("ILQR_CP") && !std::strcmp(std::getenv("ILQR_CP"), "general");  // cross-check path
+    if (h.kind == 3) return run_cp<Sys<3, 1>, 16>(st, h, bufs, nb_iter, early_stop, stream, err);
     if (h.kind == 2 && !general) return run_cpl<Sys<2, 1>, 16>(st, h, bufs, psip, nb_iter, early_stop, stream, err);
     if (h.kind == 2) return run_cp<Sys<2, 1>, 16>(st, h, bufs, nb_iter, early_stop, stream, err);
     if (h.kind == 0 && h.nd == 1 && !general) return run_cpl<Sys<0, 1>, 16>(st, h, bufs, psip, nb_iter, early_stop, stream, err);

@@ -80,11 +80,11 @@ extern "C" void ilqr_desc_defaults(ilqr_problem_desc* d) {
 
 extern "C" int ilqr_dims_of(const ilqr_problem_desc* d, ilqr_dims* o) {
     if (!d || !o) return 1;
-    if (d->kind != ILQR_SYS_POS_ORN && d->kind != ILQR_SYS_POS_ORN_TIME && d->kind != ILQR_SYS_JOINT) return 1;
+    if (d->kind != ILQR_SYS_POS_ORN && d->kind != ILQR_SYS_POS_ORN_TIME && d->kind != ILQR_SYS_JOINT && d->kind != ILQR_SYS_JOINT_TIME) return 1;
     if (d->nb_deriv != 1 && d->nb_deriv != 2) return 1;
-    if (d->kind == ILQR_SYS_JOINT) {  // JointSpacePlannerSys.cpp:71-74; its 2nd-order variant is dimensionally inconsistent upstream
+    if (d->kind == ILQR_SYS_JOINT || d->kind == ILQR_SYS_JOINT_TIME) {  // JointSpace(Time)PlannerSys localInit; 2nd order inconsistent upstream
         if (d->nb_deriv != 1) return 1;
-        o->n_x = o->n_u = o->n_f = o->n_Q = d->dof;
+        o->n_x = o->n_u = o->n_f = o->n_Q = d->dof + (d->kind == ILQR_SYS_JOINT_TIME ? 1 : 0);
         return 0;
     }
     const int tm = d->kind == ILQR_SYS_POS_ORN_TIME ? 1 : 0;
@@ -236,7 +236,7 @@ static int lower_desc(ilqr_ctx* c, const ilqr_problem_desc& d, int B, int Bp, De
     ilqr_dims dm;
     if (ilqr_dims_of(&d, &dm)) return fail(c, "unsupported system kind / nb_deriv");
     std::memset(&h, 0, sizeof(h));
-    if (!(d.kind == ILQR_SYS_JOINT && d.n_seg == 0) && lower_chain(c, d, h.chain)) return 1;  // joint-space systems need no chain
+    if (!((d.kind == ILQR_SYS_JOINT || d.kind == ILQR_SYS_JOINT_TIME) && d.n_seg == 0) && lower_chain(c, d, h.chain)) return 1;  // joint-space systems need no chain
     if (d.horizon < 2) return fail(c, "horizon must be >= 2");
     h.kind = d.kind; h.nd = d.nb_deriv; h.T = d.horizon; h.B = B; h.Bp = Bp; h.dt = d.dt;
     for (int i = 0; i < dm.n_u; i++) h.R_diag[i] = d.R_diag[i];
@@ -542,7 +542,7 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
             } else if (line_search) {
                 ProfScope ps(c, ILQR_PROF_APPLY);
                 static const bool tile_apply = std::getenv("ILQR_APPLY") && !std::strcmp(std::getenv("ILQR_APPLY"), "tile");
-                if (kind == 1 && !tile_apply) launch_apply_rows_tm(nd, p->bufs, p->B, c->stream, f);  // 8 lanes per instance
+                if ((kind == 1 || kind == 3) && !tile_apply) launch_apply_rows_tm(kind, nd, p->bufs, p->B, c->stream, f);  // 8 lanes per instance
                 else launch_solver_v2(kind, nd, KER_FWD_APPLY, al, p->bufs, p->B, p->T, c->stream, f);
             }
             if (al && !fwd_wave) {  // active-set weights of the accepted trajectory (+ multiplier update every `lag` iterations)

@@ -56,8 +56,9 @@ template <int KIND_, int ND_>
 struct Sys {
     // KIND 0 = PosOrnPlannerSys, 1 = PosOrnTimePlannerSys, 2 = JointSpacePlannerSys (target space = state space, J = I;
     // JointSpacePlannerSys.cpp:71-81, nb_deriv = 1 only: the reference's 2nd-order variant is dimensionally inconsistent)
-    static constexpr int KIND = KIND_, ND = ND_, TM = (KIND_ == 1) ? 1 : 0;
-    static constexpr bool JOINT = (KIND_ == 2);
+    // KIND 3 = JointSpaceTimePlannerSys (joint space + time state, dt = u_last^2; nb_deriv = 1)
+    static constexpr int KIND = KIND_, ND = ND_, TM = (KIND_ == 1 || KIND_ == 3) ? 1 : 0;
+    static constexpr bool JOINT = (KIND_ == 2 || KIND_ == 3);
     static constexpr int NX = ND_ * DOF + TM;
     static constexpr int NU = DOF + TM;
     static constexpr int NF = JOINT ? NX : 7 * ND_ + TM;

@@ -461,6 +461,7 @@ static void launch_solver_kernel(int which, bool al, const Bufs& a, int B, hipSt
 
 void launch_solver(int kind, int nd, int which, bool al, const Bufs& a, int B, hipStream_t st, const FwdArgs& f) {
     if (kind == 2) launch_solver_kernel<Sys<2, 1>>(which, al, a, B, st, f);
+    else if (kind == 3) launch_solver_kernel<Sys<3, 1>>(which, al, a, B, st, f);
     else if (kind == 0 && nd == 1) launch_solver_kernel<Sys<0, 1>>(which, al, a, B, st, f);
     else if (kind == 0 && nd == 2) launch_solver_kernel<Sys<0, 2>>(which, al, a, B, st, f);
     else if (kind == 1 && nd == 1) launch_solver_kernel<Sys<1, 1>>(which, al, a, B, st, f);
@@ -470,6 +471,7 @@ void launch_solver(int kind, int nd, int which, bool al, const Bufs& a, int B, h
 void launch_fx_all(int kind, int nd, const Bufs& a, int B, int T, double* out, hipStream_t st) {
     const dim3 grid((B + 63) / 64, T), block(64);
     if (kind == 2) hipLaunchKernelGGL((k_fx_all<Sys<2, 1>>), grid, block, 0, st, a, out);
+    else if (kind == 3) hipLaunchKernelGGL((k_fx_all<Sys<3, 1>>), grid, block, 0, st, a, out);
     else if (kind == 0 && nd == 1) hipLaunchKernelGGL((k_fx_all<Sys<0, 1>>), grid, block, 0, st, a, out);
     else if (kind == 0 && nd == 2) hipLaunchKernelGGL((k_fx_all<Sys<0, 2>>), grid, block, 0, st, a, out);
     else if (kind == 1 && nd == 1) hipLaunchKernelGGL((k_fx_all<Sys<1, 1>>), grid, block, 0, st, a, out);

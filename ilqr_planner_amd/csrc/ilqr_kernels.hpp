@@ -71,7 +71,7 @@ void launch_backward_mfma(int kind, int nd, bool al, const Bufs& a, int B, hipSt
 bool backward_gen_supported(int kind, int nd, bool al, int m);
 void launch_backward_gen(int kind, int nd, bool al, const Bufs& a, int B, hipStream_t st);  // needs KER_KP_DERIVS first
 bool forward_rows_supported(int kind, int nd, int n_alpha);
-void launch_apply_rows_tm(int nd, const Bufs& a, int B, hipStream_t st, const FwdArgs& f);  // time systems: re-roll of the winner, 8 lanes per instance
+void launch_apply_rows_tm(int kind, int nd, const Bufs& a, int B, hipStream_t st, const FwdArgs& f);  // time systems: re-roll of the winner, 8 lanes per instance
 void launch_forward_rows(int nd, int which, const Bufs& a, int B, hipStream_t st, const FwdArgs& f);
 void launch_forward_lin(int nd, int which, const Bufs& a, int B, int T, hipStream_t st, const FwdArgs& f);
 bool forward_wave_supported(int kind, int nd, int n_alpha);

@@ -384,7 +384,8 @@ static void launch_gen_sys(bool al, const Bufs& a, int B, hipStream_t st) {
 }
 
 void launch_backward_gen(int kind, int nd, bool al, const Bufs& a, int B, hipStream_t st) {
-    if (kind == 0 && nd == 1) launch_gen_sys<Sys<0, 1>>(al, a, B, st);
+    if (kind == 3) launch_gen_sys<Sys<3, 1>>(al, a, B, st);
+    else if (kind == 0 && nd == 1) launch_gen_sys<Sys<0, 1>>(al, a, B, st);
     else if (kind == 0 && nd == 2) launch_gen_sys<Sys<0, 2>>(al, a, B, st);
     else if (kind == 1 && nd == 1) launch_gen_sys<Sys<1, 1>>(al, a, B, st);
     else launch_gen_sys<Sys<1, 2>>(al, a, B, st);

@@ -670,9 +670,10 @@ static void launch_rows_sys(int which, const Bufs& a, int B, hipStream_t st, con
     }
 }
 
-void launch_apply_rows_tm(int nd, const Bufs& a, int B, hipStream_t st, const FwdArgs& f) {
+void launch_apply_rows_tm(int kind, int nd, const Bufs& a, int B, hipStream_t st, const FwdArgs& f) {
     const dim3 grid(grid_x8((B + 7) / 8)), block(64);
-    if (nd == 1) hipLaunchKernelGGL((k_apply_rows_tm<Sys<1, 1>>), grid, block, 0, st, a, f);
+    if (kind == 3) hipLaunchKernelGGL((k_apply_rows_tm<Sys<3, 1>>), grid, block, 0, st, a, f);
+    else if (nd == 1) hipLaunchKernelGGL((k_apply_rows_tm<Sys<1, 1>>), grid, block, 0, st, a, f);
     else hipLaunchKernelGGL((k_apply_rows_tm<Sys<1, 2>>), grid, block, 0, st, a, f);
 }
 

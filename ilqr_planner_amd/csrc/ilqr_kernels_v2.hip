@@ -622,6 +622,7 @@ void launch_solver_v2(int kind, int nd, int which, bool al, const Bufs& a, int B
         return;
     }
     if (kind == 2) launch_v2_kernel<Sys<2, 1>>(which, a, B, T, st, f);
+    else if (kind == 3) launch_v2_kernel<Sys<3, 1>>(which, a, B, T, st, f);
     else if (kind == 0 && nd == 1) launch_v2_kernel<Sys<0, 1>>(which, a, B, T, st, f);
     else if (kind == 0 && nd == 2) launch_v2_kernel<Sys<0, 2>>(which, a, B, T, st, f);
     else if (kind == 1 && nd == 1) launch_v2_kernel<Sys<1, 1>>(which, a, B, T, st, f);

@@ -32,6 +32,9 @@ def config(name: str):
         # 3 joints are padded to the 7 the kernels are built for (zero precision, zero limit weight, u = 0 keeps them at rest).
         "C1": dict(kind=capi.SYS_JOINT, nb_deriv=1, T=50, dt=0.1, B=1, seed=0, dof=3, q0=[np.pi / 4] * 3, Qdiag=[[1, 1, 1]] * 2, solver="recursive",
                    nb_iter=10),
+        # JointSpaceTimePlannerSys: joint targets with a free duration (time state, dt = u_last^2), AngularTimeKeypoint targets
+        "C1t": dict(kind=capi.SYS_JOINT_TIME, nb_deriv=1, T=60, dt=None, B=128, seed=11, dof=7, Qdiag=[[1] * 7 + [0], [1] * 7 + [.1]], ctimes=[2.0, 4.0],
+                    solver="recursive", nb_iter=10),
         "C1j": dict(kind=capi.SYS_JOINT, nb_deriv=1, T=100, dt=0.1, B=256, seed=10, dof=7, Qdiag=[[1] * 7, [1, .5, 1, .5, 1, .5, 1]], solver="recursive",
                     nb_iter=8),
         # C2: "pos-only" = zero orientation precision (POS_ORN_MULTI_SYS.ipynb cell 12)
@@ -64,7 +67,7 @@ def make_batch(ctx: capi.Context, cfg: dict, B: int | None = None, seed: int | N
     """Returns (desc, inputs) where inputs = dict(q0, dq0, targets[list per keypoint], U0, [A, b, lambda0])."""
     B = int(B if B is not None else cfg["B"])
     seed = int(seed if seed is not None else cfg["seed"])
-    if cfg["kind"] == capi.SYS_JOINT:
+    if cfg["kind"] in (capi.SYS_JOINT, capi.SYS_JOINT_TIME):
         return _make_joint_batch(cfg, B, seed, limits)
     chain = chain or panda_chain()
     dof = chain["dof"]
@@ -111,31 +114,39 @@ def make_batch(ctx: capi.Context, cfg: dict, B: int | None = None, seed: int | N
 
 
 def _make_joint_batch(cfg, B, seed, limits):
-    """JointSpacePlannerSys batches (AngularKeypoint targets); `dof` < 7 joints are padded to the device's 7."""
+    """JointSpace(Time)PlannerSys batches (Angular(Time)Keypoint targets); `dof` < 7 joints are padded to the device's 7."""
     rng = np.random.default_rng(seed)
     T, dofu, D = cfg["T"], cfg.get("dof", 7), 7
+    tm = 1 if cfg["kind"] == capi.SYS_JOINT_TIME else 0
+    n = D + tm
     kp_t = [T // 2 - 1, T - 1]
     lim = 10 * np.pi if limits == "inactive" else 2.0
-    smax, smin, w = np.zeros(D), np.zeros(D), np.zeros(D, dtype=int)
+    smax, smin, w = np.zeros(n), np.zeros(n), np.zeros(n, dtype=int)
     smax[:dofu], smin[:dofu], w[:dofu] = lim, -lim, 1
     chain = dict(dof=D, seg_joint=[], seg_xyz=[], seg_R=[], seg_axis=[])  # no kinematic chain: f(x) = x
     kp_Q = []
     for q in cfg["Qdiag"]:
-        Q = np.zeros((D, D))
-        Q[:dofu, :dofu] = np.diag(q)
+        Q = np.zeros((n, n))
+        Q[:dofu, :dofu] = np.diag(q[:dofu])
+        if tm:
+            Q[D, D] = q[-1]
         kp_Q.append(Q)
-    desc = capi.make_desc(kind=capi.SYS_JOINT, nb_deriv=1, horizon=T, dt=cfg["dt"], R_diag=[1e-5] * D, chain=chain, kp_timesteps=kp_t, kp_Q=kp_Q,
+    desc = capi.make_desc(kind=cfg["kind"], nb_deriv=1, horizon=T, dt=cfg["dt"], R_diag=[1e-5] * n, chain=chain, kp_timesteps=kp_t, kp_Q=kp_Q,
                           limits=dict(state_max=smax, state_min=smin, limit_weight=w, penalty=1.0))
     q0 = np.zeros((B, D))
     base = np.asarray(cfg.get("q0", [0.0] * dofu), float)
     q0[:, :dofu] = base[None, :] + (rng.uniform(-0.3, 0.3, (B, dofu)) if B > 1 else 0.0)
     targets = []
-    for _ in range(2):
-        t = np.zeros((B, D))
-        t[:, :dofu] = rng.uniform(-2.5, 2.5, (B, dofu))
+    for i in range(2):
+        t = np.zeros((B, n))
+        t[:, :dofu] = rng.uniform(-2.5, 2.5, (B, dofu)) if not tm else rng.uniform(-1.0, 1.0, (B, dofu))
+        if tm:
+            t[:, D] = cfg["ctimes"][i]
         targets.append(t)
-    inp = dict(q0=q0, dq0=np.zeros((B, D)), targets=targets, U0=np.zeros((B, T - 1, D)), kp_t=kp_t, dof=dofu,
-               limits=dict(state_max=smax, state_min=smin, limit_weight=w))
+    U0 = np.zeros((B, T - 1, n))
+    if tm:
+        U0[:, :, -1] = 0.01  # as the time-system tutorials start (POS_ORN_TIME_SYS.ipynb cell 8)
+    inp = dict(q0=q0, dq0=np.zeros((B, D)), targets=targets, U0=U0, kp_t=kp_t, dof=dofu, limits=dict(state_max=smax, state_min=smin, limit_weight=w))
     return desc, inp
 
 

@@ -40,6 +40,8 @@ extern "C" {
 #define ILQR_SYS_POS_ORN_TIME 1 /* sys::PosOrnTimePlannerSys  (src/system/PosOrnTimePlannerSys.cpp) */
 #define ILQR_SYS_JOINT 2        /* sys::JointSpacePlannerSys  (src/system/JointSpacePlannerSys.cpp), nb_deriv = 1: target space = joint
                                    space, J = I, AngularKeypoint targets (n_f = n_Q = dof); no chain needed (n_seg may be 0) */
+#define ILQR_SYS_JOINT_TIME 3   /* sys::JointSpaceTimePlannerSys (src/system/JointSpaceTimePlannerSys.cpp), nb_deriv = 1: joint space +
+                                   time state, dt = u_last^2, AngularTimeKeypoint targets [q*, t*] */
 
 /* per-instance status word */
 #define ILQR_STATUS_OK 0

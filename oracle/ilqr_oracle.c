@@ -247,12 +247,12 @@ void orc_fk(const orc_chain* c, const double* q, const double* dq,
 
 void orc_system_finalize(orc_system* s) {
     s->dof = s->chain.dof;
-    int tm = (s->kind == ORC_SYS_POS_ORN_TIME) ? 1 : 0;
+    int tm = ORC_IS_TM(s->kind) ? 1 : 0;
     s->n_x = s->nb_deriv * s->dof + tm;  /* PosOrnPlannerSys.cpp:74 / PosOrnTimePlannerSys.cpp:67 */
     s->n_u = s->dof + tm;                /* :75 / :68 */
     s->n_f = 7 * s->nb_deriv + tm;       /* :76 / :69 */
     s->n_Q = s->n_f - s->nb_deriv;       /* :77 / :70 */
-    if (s->kind == ORC_SYS_JOINT) {      /* JointSpacePlannerSys.cpp:71-74: target space = state space */
+    if (ORC_IS_JOINT(s->kind)) {         /* JointSpacePlannerSys.cpp:71-74, JointSpaceTimePlannerSys.cpp:62-65: target space = state space */
         s->n_f = s->n_x;
         s->n_Q = s->n_x;
     }
@@ -297,8 +297,8 @@ static void eig_mat_to_quat(const double m[9], double q[4]) {
  * (TransformedSimulationInterface.cpp:53-103): p' = R'(p - t), R_ee' = R' R_ee -> Eigen quaternion, J' = blkdiag(R,R)' J,
  * dx' = R' dx, w' = R' w. */
 static void fx_jac_frame(const orc_system* s, const orc_keypoint* kp, const double* x, double* fx, double* J) {
-    int dof = s->dof, nd = s->nb_deriv, tm = (s->kind == ORC_SYS_POS_ORN_TIME);
-    if (s->kind == ORC_SYS_JOINT) { /* JointSpacePlannerSys::getFxJac, JointSpacePlannerSys.cpp:77-81: f(x) = x, J = I */
+    int dof = s->dof, nd = s->nb_deriv, tm = ORC_IS_TM(s->kind);
+    if (ORC_IS_JOINT(s->kind)) { /* JointSpace(Time)PlannerSys::getFxJac: f(x) = x (time state included), J = I */
         if (fx) memcpy(fx, x, sizeof(double) * s->n_f);
         if (J) {
             memset(J, 0, sizeof(double) * s->n_Q * s->n_x);
@@ -366,8 +366,8 @@ void orc_get_fx_jac(const orc_system* s, const double* x, double* fx, double* J)
 
 /* PosOrnKeypoint::diff (PosOrnKeypoint.cpp:24-45), SpacetimeKeypoint::diff (SpacetimeKeypoint.cpp:19-25) */
 void orc_kp_diff(const orc_system* s, const orc_keypoint* kp, const double* fx, double* e) {
-    int nd = s->nb_deriv, tm = (s->kind == ORC_SYS_POS_ORN_TIME);
-    if (s->kind == ORC_SYS_JOINT) { /* AngularKeypoint::diff, AngularKeypoint.cpp:24-27: target - state */
+    int nd = s->nb_deriv, tm = ORC_IS_TM(s->kind);
+    if (ORC_IS_JOINT(s->kind)) { /* AngularKeypoint::diff (AngularKeypoint.cpp:24-27), AngularTimeKeypoint::diff (:22-27): target - state, t* - t last */
         for (int i = 0; i < s->n_Q; i++) e[i] = kp->jt[i] - fx[i];
         return;
     }
@@ -494,7 +494,7 @@ void orc_cost_xx(const orc_system* s, const double* x, int k, double* lxx) {
  * as reset(); step; step; ... so x is the simulator's own state: quirk D-7). */
 void orc_step(const orc_system* s, const double* x, const double* u,
               double* x_next, double* fx_next, double* A, double* B, double* J) {
-    int dof = s->dof, nd = s->nb_deriv, nx = s->n_x, nu = s->n_u, tm = (s->kind == ORC_SYS_POS_ORN_TIME);
+    int dof = s->dof, nd = s->nb_deriv, nx = s->n_x, nu = s->n_u, tm = ORC_IS_TM(s->kind);
     double xn[ORC_MAX_NX];
     double dtSqrt = tm ? u[nu - 1] : 0.0;
     double dt = tm ? dtSqrt * dtSqrt : s->dt;

@@ -32,7 +32,10 @@ extern "C" {
 #define ORC_MAX_KP 8
 #define ORC_MAX_M 32
 
-enum { ORC_SYS_POS_ORN = 0, ORC_SYS_POS_ORN_TIME = 1, ORC_SYS_JOINT = 2 /* JointSpacePlannerSys, nb_deriv = 1 (App. D-10: 2 is broken upstream) */ };
+enum { ORC_SYS_POS_ORN = 0, ORC_SYS_POS_ORN_TIME = 1, ORC_SYS_JOINT = 2 /* JointSpacePlannerSys, nb_deriv = 1 (App. D-10: 2 is broken upstream) */,
+       ORC_SYS_JOINT_TIME = 3 /* JointSpaceTimePlannerSys, nb_deriv = 1 */ };
+#define ORC_IS_TM(kind) ((kind) == ORC_SYS_POS_ORN_TIME || (kind) == ORC_SYS_JOINT_TIME)
+#define ORC_IS_JOINT(kind) ((kind) == ORC_SYS_JOINT || (kind) == ORC_SYS_JOINT_TIME)
 
 /* URDF chain base->tip, as orocos_kdl sees it after TinyURDFParser: one segment per URDF joint,
  * T_seg(q) = Trans(xyz) * R_fixed * Rot(axis, q)  (fixed joints: no Rot), then the user tool frame

@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "libilqr_oracle.so")
 
 MAX_SEG, MAX_DOF, MAX_NX, MAX_NU, MAX_NF, MAX_NQ, MAX_KP = 24, 7, 16, 8, 16, 14, 8
-SYS_POS_ORN, SYS_POS_ORN_TIME, SYS_JOINT = 0, 1, 2
+SYS_POS_ORN, SYS_POS_ORN_TIME, SYS_JOINT, SYS_JOINT_TIME = 0, 1, 2, 3
 
 
 class Chain(C.Structure):
@@ -270,8 +270,9 @@ def make_system(segs, kind, nb_deriv, T, dt, R_diag, keypoints, q0, dq0=None, qM
     for i, k in enumerate(kps):
         kp = s.kp[i]
         kp.timestep = int(k["timestep"])
-        if kind == SYS_JOINT:  # AngularKeypoint: the target is a joint vector
-            for j, v in enumerate(k["target"]):
+        if kind in (SYS_JOINT, SYS_JOINT_TIME):  # AngularKeypoint / AngularTimeKeypoint: joint vector (+ continuous time last)
+            tgt = list(k["target"]) + ([float(k["ctime"])] if kind == SYS_JOINT_TIME else [])
+            for j, v in enumerate(tgt):
                 kp.jt[j] = float(v)
         else:
             for j in range(3):

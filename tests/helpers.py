@@ -78,13 +78,20 @@ def assert_trace(got_cost, got_alpha, trace, ulps=0.51):
 
 def oracle_system_of_instance(cfg, inp, i, segs=None):
     """Oracle System for instance i of a batch made by ilqr_planner_amd.workloads.make_batch."""
-    if cfg["kind"] == 2:  # JointSpacePlannerSys with its TRUE number of joints (the device batch is padded to 7)
+    if cfg["kind"] in (2, 3):  # JointSpace(Time)PlannerSys with its TRUE number of joints (the device batch is padded to 7)
         n = inp.get("dof", 7)
+        tm = cfg["kind"] == 3
         segs_j = dict(dof=n, seg_joint=list(range(n)), seg_xyz=[[0, 0, 0]] * n, seg_axis=[[0, 0, 1]] * n, seg_R=[[1, 0, 0, 0, 1, 0, 0, 0, 1]] * n)
-        kps = [dict(timestep=ts, target=inp["targets"][k][i][:n], Q=np.diag(cfg["Qdiag"][k])) for k, ts in enumerate(inp["kp_t"])]
+        kps = []
+        for k, ts in enumerate(inp["kp_t"]):
+            qd = list(cfg["Qdiag"][k][:n]) + ([cfg["Qdiag"][k][-1]] if tm else [])
+            d = dict(timestep=ts, target=inp["targets"][k][i][:n], Q=np.diag(qd))
+            if tm:
+                d["ctime"] = inp["targets"][k][i][-1]
+            kps.append(d)
         lim = inp["limits"]
-        return orc.make_system(segs_j, orc.SYS_JOINT, 1, cfg["T"], cfg["dt"], [1e-5] * n, kps, inp["q0"][i][:n], [0.0] * n,
-                               lim["state_max"][:n], lim["state_min"][:n])
+        return orc.make_system(segs_j, orc.SYS_JOINT_TIME if tm else orc.SYS_JOINT, 1, cfg["T"], cfg["dt"], [1e-5] * (n + (1 if tm else 0)), kps,
+                               inp["q0"][i][:n], [0.0] * n, lim["state_max"][:n], lim["state_min"][:n])
     segs = segs or panda_segs()
     nd = cfg["nb_deriv"]
     tm = cfg["kind"] == 1
@@ -111,7 +118,11 @@ def oracle_system_of_instance(cfg, inp, i, segs=None):
 
 def oracle_solve_instance(cfg, inp, i, nb_iter, early_stop, segs=None):
     s = oracle_system_of_instance(cfg, inp, i, segs)
-    U0 = inp["U0"][i][:, : s.n_u].reshape(-1)  # joint-space batches are padded to 7 joints on the device only
+    U0 = inp["U0"][i]
+    if cfg["kind"] in (2, 3) and inp.get("dof", 7) < 7:  # joint-space batches are padded to 7 joints on the device only
+        n = inp["dof"]
+        U0 = np.hstack([U0[:, :n], U0[:, 7:]])
+    U0 = U0.reshape(-1)
     if cfg["solver"] == "recursive":
         return orc.solve_recursive(s, U0, nb_iter, True, early_stop)
     if cfg["solver"] == "al":

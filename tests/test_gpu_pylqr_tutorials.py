@@ -289,3 +289,33 @@ def test_joint_space_tutorial(capsys):
     for u in np.asarray(U1).reshape((horizon - 1, nb_ctrl_var)):
         rbt.send_vel(dt, u, True)
     np.testing.assert_allclose(rbt.get_q(), target_2, atol=5e-2)
+
+
+def test_joint_space_time_system(capsys):
+    """JOINT_SPACE_SYS_TIME.ipynb's classes: JointSpaceTimePlannerSys + AngularTimeKeypoint (the duration is optimised with the motion)."""
+    from PyLQR.sim import KDLRobot
+    from PyLQR.solver import ILQRRecursive
+    from PyLQR.system import AngularTimeKeypoint, JointSpaceTimePlannerSys
+    from PyLQR.utils import PythonCallbackMessage
+
+    dof, horizon = 7, 60
+    q0 = [0.0] * dof
+    qMax = np.array([np.pi] * dof) * 10
+    rbt = KDLRobot(URDF, "panda_link0", "panda_tip", q0, [0] * dof)
+    rng = np.random.default_rng(7)
+    t1, t2 = rng.uniform(-1, 1, dof), rng.uniform(-1, 1, dof)
+    kp1 = AngularTimeKeypoint(t1, np.diag([1.0] * dof + [0.0]), 2.0, horizon // 2 - 1)
+    kp2 = AngularTimeKeypoint(t2, np.diag([1.0] * dof + [0.1]), 4.0, horizon - 1)
+    np.testing.assert_allclose(kp2.diff(np.array(q0 + [1.0])), list(t2) + [3.0])
+    sys_ = JointSpaceTimePlannerSys(rbt, [kp1, kp2], [1e-5] * (dof + 1), qMax, -qMax, horizon, 1)
+    assert (sys_.get_nb_state_var(), sys_.get_nb_ctrl_var(), sys_.get_nb_target_var()) == (8, 8, 8)
+    u0 = np.tile(np.array([0.0] * dof + [0.01]), (horizon - 1, 1))
+    cb = PythonCallbackMessage()
+    capsys.readouterr()
+    X, F_X, U, K, k, cost = ILQRRecursive(sys_).solve(u0, 25, True, True, cb)
+    lines = capsys.readouterr().out.strip().splitlines()
+    costs = [float(LINE.match(l).group(2)) for l in lines]
+    assert costs[-1] < 1e-2 * costs[0]
+    X = np.asarray(X)
+    np.testing.assert_allclose(X[-1][:dof], t2, atol=5e-2)
+    assert 2.0 < X[-1][-1] < 6.0  # the total duration settles near the 4 s target
