@@ -263,6 +263,45 @@ bool KDLRobot::lowerChain(ilqr_problem_desc* d) const {
     return true;
 }
 
+// ---- Robot2D (2DRobot.cpp:13-74)
+Robot2D::Robot2D(const Vec& lengths, const Vec& default_q) : lengths_(lengths) {
+    if (lengths.size() != default_q.size()) throw std::runtime_error("[Robot2D] lengths and default_q must have the same size");
+    dof = (int)default_q.size();
+    nbCarDim = 2;
+    q = default_q;
+    dq.assign(dof, 0.0);
+    ddq.assign(dof, 0.0);
+    x.assign(2, 0.0);
+    dx.assign(2, 0.0);
+    w.assign(3, 0.0);
+    ornQuat = {1, 0, 0, 0};
+    updateKinematics();
+}
+Vec Robot2D::fkine(const Vec& q_) {
+    Vec xi(2, 0.0);
+    for (int i = 0; i < dof; i++) {
+        xi[0] += lengths_[i] * std::cos(q_[i]);
+        xi[1] += lengths_[i] * std::sin(q_[i]);
+    }
+    return xi;
+}
+void Robot2D::updateKinematics() {
+    x = fkine();
+    const double h = M_PI * 1e-3;
+    Jac = Mat(4, dof);
+    const Vec old_pos = fkine();
+    for (int i = 0; i < dof; i++) {
+        Vec qi = q;
+        qi[i] += h;
+        const Vec new_pos = fkine(qi);
+        Jac(0, i) = (new_pos[0] - old_pos[0]) / h;
+        Jac(1, i) = (new_pos[1] - old_pos[1]) / h;
+    }
+    dx.assign(2, 0.0);
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < dof; j++) dx[i] += Jac(i, j) * dq[j];
+}
+
 // ---- TransformedSimulationInterface (TransformedSimulationInterface.cpp:20-103)
 TransformedSimulationInterface::TransformedSimulationInterface(const std::shared_ptr<SimulationInterface>& r, const Mat& T) : r_(r), T_(T) {
     if (!r) throw std::runtime_error("[TransformedSimulationInterface] Object is not initialized");  // :33
@@ -697,6 +736,30 @@ Vec PosOrnPlannerSys::getState() {
 }
 void PosOrnPlannerSys::reset() { r->setConfiguration(q0_, dq0_); }
 
+// A joint-space descriptor of n < 7 joints widened to the 7 the device kernels are built for: the extra joints get zero precision,
+// zero limit weight and the first joint's control penalty; with u = 0 they stay at rest, so the n-joint problem is unchanged.
+static void pad_joint_desc(ilqr_problem_desc* d, int n, int tm) {
+    if (n >= 7) return;
+    const int D = 7, nu_old = n + tm, nx_old = n + tm, nn = D + tm;
+    double R[ILQR_MAX_NU];
+    for (int i = 0; i < D; i++) R[i] = d->R_diag[i < n ? i : 0];
+    if (tm) R[D] = d->R_diag[nu_old - 1];
+    for (int i = 0; i < nn; i++) d->R_diag[i] = R[i];
+    double smax[ILQR_MAX_NX + 1] = {0}, smin[ILQR_MAX_NX + 1] = {0};
+    int lw[ILQR_MAX_NX + 1] = {0};
+    for (int i = 0; i < n; i++) { smax[i] = d->state_max[i]; smin[i] = d->state_min[i]; lw[i] = d->limit_weight[i]; }
+    for (int i = 0; i < nn; i++) { d->state_max[i] = smax[i]; d->state_min[i] = smin[i]; d->limit_weight[i] = lw[i]; }
+    for (int k = 0; k < d->n_kp; k++) {
+        std::vector<double> Q((size_t)nn * nn, 0.0);
+        auto map = [&](int i) { return i < n ? i : D; };  // user index -> device index (the time entry moves to the end)
+        for (int a = 0; a < nx_old; a++)
+            for (int b = 0; b < nx_old; b++) Q[(size_t)map(a) * nn + map(b)] = d->kp_Q[k][a * nx_old + b];
+        for (int i = 0; i < nn * nn; i++) d->kp_Q[k][i] = Q[i];
+    }
+    d->dof = D;
+    d->n_seg = 0;
+}
+
 // ---- AngularKeypoint (AngularKeypoint.cpp:15-27), JointSpacePlannerSys (JointSpacePlannerSys.cpp:50-122)
 Vec AngularKeypoint::getState() const {
     Vec st = position_;
@@ -740,8 +803,9 @@ Vec JointSpacePlannerSys::getState() {
 void JointSpacePlannerSys::reset() { r->setConfiguration(q0_, dq0_); }
 void JointSpacePlannerSys::lower(ilqr_problem_desc* d) const {
     if (nb_deriv_ != 1) throw std::runtime_error("[ilqr_hip] JointSpacePlannerSys is lowered for nbDeriv = 1 only (the 2nd-order variant is inconsistent upstream)");
-    if (r->getDOF() != 7) throw std::runtime_error("[ilqr_hip] joint-space systems are lowered for 7 joints (pad smaller robots: zero precision, zero limit weight)");
+    if (r->getDOF() > 7) throw std::runtime_error("[ilqr_hip] joint-space systems are lowered for at most 7 joints");
     System::lower(d);  // f(x) = x needs no chain, but a KDLRobot's chain is kept for ilqr_fk_batch users
+    pad_joint_desc(d, r->getDOF(), 0);
 }
 
 // ---- AngularTimeKeypoint (AngularTimeKeypoint.cpp:15-30), JointSpaceTimePlannerSys (JointSpaceTimePlannerSys.cpp:50-160)
@@ -791,8 +855,9 @@ Vec JointSpaceTimePlannerSys::getState() {
 void JointSpaceTimePlannerSys::reset() { r->setConfiguration(q0_, dq0_); }
 void JointSpaceTimePlannerSys::lower(ilqr_problem_desc* d) const {
     if (nb_deriv_ != 1) throw std::runtime_error("[ilqr_hip] JointSpaceTimePlannerSys is lowered for nbDeriv = 1 only");
-    if (r->getDOF() != 7) throw std::runtime_error("[ilqr_hip] joint-space systems are lowered for 7 joints");
+    if (r->getDOF() > 7) throw std::runtime_error("[ilqr_hip] joint-space systems are lowered for at most 7 joints");
     System::lower(d);
+    pad_joint_desc(d, r->getDOF(), 1);
 }
 
 PosOrnTimePlannerSys::PosOrnTimePlannerSys(const std::shared_ptr<sim::SimulationInterface>& r, const std::vector<std::shared_ptr<Keypoint>>& kps, const Vec& Rt,
@@ -865,6 +930,68 @@ static BatchResult run_batch(sys::System& s, const BatchInputs& in, int nb_iter,
     ilqr_ctx* ctx = device_context();
     const int B = in.B, T = d.horizon, dof = d.dof;
     if (B <= 0) throw std::runtime_error("[ilqr_hip] batch must be positive");
+    static thread_local bool widened = false;  // set while the widened problem of a padded joint-space system runs
+    const int padn = widened ? 0 : s.paddedFromDof();  // joint-space system of padn < 7 joints: inputs widened, outputs narrowed again
+    if (padn > 0) {
+        const int tm = (d.kind == ILQR_SYS_JOINT_TIME) ? 1 : 0, D = 7, wo = padn + tm, wn = D + tm;
+        auto widen = [&](const std::vector<double>& v, size_t rows) {  // [rows][wo] -> [rows][wn], the time entry moves to the end
+            std::vector<double> o(rows * wn, 0.0);
+            for (size_t r_ = 0; r_ < rows; r_++) {
+                for (int i = 0; i < padn; i++) o[r_ * wn + i] = v[r_ * wo + i];
+                if (tm) o[r_ * wn + D] = v[r_ * wo + padn];
+            }
+            return o;
+        };
+        auto narrow = [&](const std::vector<double>& v, size_t rows) {
+            std::vector<double> o(rows * wo, 0.0);
+            for (size_t r_ = 0; r_ < rows; r_++) {
+                for (int i = 0; i < padn; i++) o[r_ * wo + i] = v[r_ * wn + i];
+                if (tm) o[r_ * wo + padn] = v[r_ * wn + D];
+            }
+            return o;
+        };
+        BatchInputs in2 = in;
+        auto pad_q = [&](const std::vector<double>& v, const Vec& dflt) {
+            std::vector<double> src = v;
+            if (src.empty()) for (int b_ = 0; b_ < B; b_++) src.insert(src.end(), dflt.begin(), dflt.end());
+            std::vector<double> o((size_t)B * D, 0.0);
+            for (int b_ = 0; b_ < B; b_++) for (int i = 0; i < padn; i++) o[(size_t)b_ * D + i] = src[(size_t)b_ * padn + i];
+            return o;
+        };
+        in2.q0 = pad_q(in.q0, s.q0());
+        in2.dq0 = pad_q(in.dq0, s.dq0());
+        const auto& kps_ = s.getKeypoints();
+        in2.kp_targets.assign(kps_.size(), {});
+        for (size_t k = 0; k < kps_.size(); k++) {
+            std::vector<double> tg = (k < in.kp_targets.size() && !in.kp_targets[k].empty()) ? in.kp_targets[k] : std::vector<double>();
+            if (tg.empty()) for (int b_ = 0; b_ < B; b_++) { const Vec t_ = kps_[k]->targetFx(); tg.insert(tg.end(), t_.begin(), t_.end()); }
+            in2.kp_targets[k] = widen(tg, B);
+        }
+        const size_t nUo = (size_t)(T - 1) * wo;
+        std::vector<double> U0o = in.U0;
+        if (U0o.size() == nUo) { std::vector<double> t_; for (int b_ = 0; b_ < B; b_++) t_.insert(t_.end(), in.U0.begin(), in.U0.end()); U0o = t_; }
+        if (U0o.size() != nUo * B) throw std::runtime_error("[ilqr_hip] U0 must be (T-1) x nb_ctrl_var per instance");
+        in2.U0 = widen(U0o, (size_t)B * (T - 1));
+        // run on the widened problem (the descriptor is already widened by lower()), then narrow the outputs
+        widened = true;
+        BatchResult r;
+        try { r = run_batch(s, in2, nb_iter, gains, &d, pre_solve, solve, post_solve); } catch (...) { widened = false; throw; }
+        widened = false;
+        r.X = narrow(r.X, (size_t)B * T);
+        r.U = narrow(r.U, (size_t)B * (T - 1));
+        if (!r.fX.empty()) r.fX = narrow(r.fX, (size_t)B * T);
+        if (!r.d.empty()) r.d = narrow(r.d, (size_t)B * (T - 1));
+        if (!r.K.empty()) {  // [B][T-1][wn][wn] -> [B][T-1][wo][wo]
+            std::vector<double> Ko((size_t)B * (T - 1) * wo * wo, 0.0);
+            auto map = [&](int i) { return i < padn ? i : D; };
+            for (size_t m_ = 0; m_ < (size_t)B * (T - 1); m_++)
+                for (int a_ = 0; a_ < wo; a_++)
+                    for (int b_ = 0; b_ < wo; b_++) Ko[(m_ * wo + a_) * wo + b_] = r.K[(m_ * wn + map(a_)) * wn + map(b_)];
+            r.K = Ko;
+        }
+        r.n_x = r.n_u = r.n_f = wo;
+        return r;
+    }
     ProblemGuard g;
     check(ilqr_problem_create(ctx, &d, B, &g.p));
     auto tile = [&](const Vec& v, size_t per) {

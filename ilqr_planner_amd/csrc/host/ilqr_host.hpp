@@ -110,6 +110,19 @@ protected:
     ilqr_problem_desc chain_;  // only the chain fields are meaningful
     Vec lower_, upper_;
 };
+// Planar arm of 2DRobot.h / 2DRobot.cpp:13-74 (host only: x = sum_i l_i [cos q_i, sin q_i] with ABSOLUTE joint angles, Jacobian by
+// forward differences of step pi*1e-3, J = [Jt; 0] (4 x dof), identity quaternion).  Only joint-space systems work with it.
+class Robot2D : public SimulationInterface {
+public:
+    Robot2D(const Vec& lengths, const Vec& default_q);
+    Vec fkine(const Vec& q);
+    Vec fkine() { return fkine(q); }
+    void updateKinematics() override;
+
+protected:
+    Vec lengths_;
+};
+
 // The wrapped robot seen from an object frame T (4x4 pose): p' = R'(p - t), R_ee' = R' R_ee, J' = blkdiag(R,R)' J
 // (TransformedSimulationInterface.h / .cpp:20-103).  The Python constructor takes (robot, T) as the reference's binding does.
 class TransformedSimulationInterface : public SimulationInterface {
@@ -258,6 +271,9 @@ public:
     Vec q0() const { return q0_; }
     Vec dq0() const { return dq0_; }
     int getNbDeriv() const { return nb_deriv_; }
+    // joint-space systems of robots with fewer than 7 joints are padded to the device's 7 (zero precision, zero limit weight, u = 0):
+    // number of joints the user sees, 0 = no padding
+    virtual int paddedFromDof() const { return 0; }
     const Vec& Rt() const { return Rdiag; }
     int kind() const { return kind_; }
 
@@ -306,6 +322,7 @@ public:
     Vec getState() override;
     void reset() override;
     void lower(ilqr_problem_desc* d) const override;
+    int paddedFromDof() const override { return r->getDOF() < 7 ? r->getDOF() : 0; }
 
 protected:
     void localInit(double dt);
@@ -323,6 +340,7 @@ public:
     Vec getState() override;
     void reset() override;
     void lower(ilqr_problem_desc* d) const override;
+    int paddedFromDof() const override { return r->getDOF() < 7 ? r->getDOF() : 0; }
 
 protected:
     void localInit();

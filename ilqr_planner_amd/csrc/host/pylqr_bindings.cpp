@@ -127,6 +127,11 @@ PYBIND11_MODULE(PyLQR, m) {
              py::arg("tip_frame"), py::arg("q"), py::arg("dq"))
         .def("joint_lower_limits", &sim::KDLRobot::jointLowerLimits)
         .def("joint_upper_limits", &sim::KDLRobot::jointUpperLimits);
+    // bindings.cpp:192-195
+    py::class_<sim::Robot2D, sim::SimulationInterface, std::shared_ptr<sim::Robot2D>>(m_sim, "Robot2D")
+        .def(py::init<const Vec&, const Vec&>(), py::arg("lengths"), py::arg("default_q"))
+        .def("fkine", static_cast<Vec (sim::Robot2D::*)()>(&sim::Robot2D::fkine))
+        .def("fkine", static_cast<Vec (sim::Robot2D::*)(const Vec&)>(&sim::Robot2D::fkine), py::arg("q"));
     // bindings.cpp:206-207: TransformedSimulationInterface(r, T)
     py::class_<sim::TransformedSimulationInterface, sim::SimulationInterface, std::shared_ptr<sim::TransformedSimulationInterface>>(m_sim, "TransformedSimulationInterface")
         .def(py::init<const std::shared_ptr<sim::SimulationInterface>&, const Mat&>(), py::arg("r"), py::arg("T"));

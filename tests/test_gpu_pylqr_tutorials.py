@@ -319,3 +319,35 @@ def test_joint_space_time_system(capsys):
     X = np.asarray(X)
     np.testing.assert_allclose(X[-1][:dof], t2, atol=5e-2)
     assert 2.0 < X[-1][-1] < 6.0  # the total duration settles near the 4 s target
+
+
+def test_config1_robot2d_joint_space(capsys):
+    """BASELINE configs[0] through PyLQR: Robot2D (3 links) + JointSpacePlannerSys, T = 50, one seed -- the 3 joints are padded to the
+    device's 7 inside the host classes; results come back 3-wide and agree with the oracle's 3-joint solve."""
+    from PyLQR.sim import Robot2D
+    from PyLQR.solver import ILQRRecursive
+    from PyLQR.system import AngularKeypoint, JointSpacePlannerSys
+    from PyLQR.utils import PythonCallbackMessage
+    from ilqr_planner_amd import workloads
+    from tests.helpers import oracle_solve_instance
+
+    cfg = workloads.config("C1")
+    _, inp = workloads._make_joint_batch(cfg, 1, cfg["seed"], "inactive")
+    rbt = Robot2D([1, 1, 1], cfg["q0"])
+    np.testing.assert_allclose(rbt.fkine(), [3 * np.cos(np.pi / 4), 3 * np.sin(np.pi / 4)])
+    T, n = cfg["T"], 3
+    kps = [AngularKeypoint(inp["targets"][k][0][:n], np.diag(cfg["Qdiag"][k]), ts) for k, ts in enumerate(inp["kp_t"])]
+    lim = inp["limits"]
+    sys_ = JointSpacePlannerSys(rbt, kps, [1e-5] * n, lim["state_max"][:n], lim["state_min"][:n], T, 1, cfg["dt"])
+    assert (sys_.get_nb_state_var(), sys_.get_nb_ctrl_var(), sys_.get_nb_target_var(), sys_.get_horizon()) == (3, 3, 3, 50)
+    cb = PythonCallbackMessage()
+    capsys.readouterr()
+    X, F_X, U, K, k, cost = ILQRRecursive(sys_).solve(np.zeros((T - 1, n)), 10, True, True, cb)
+    lines = capsys.readouterr().out.strip().splitlines()
+    r = oracle_solve_instance(cfg, inp, 0, 10, True)
+    assert len(lines) == r["iters"] == 2
+    assert np.asarray(X).shape == (T, n) and np.asarray(U).shape == (T - 1, n) and np.asarray(K).shape == (T - 1, n, n)
+    np.testing.assert_allclose(cost, r["cost"], rtol=1e-7)
+    np.testing.assert_allclose(np.asarray(X), r["X"], atol=1e-9)
+    np.testing.assert_allclose(np.asarray(U), r["U"], atol=1e-8)
+    np.testing.assert_allclose(rbt.get_q(), cfg["q0"])  # left at reset()
