@@ -1,17 +1,22 @@
-// ilqr_kernels_wave.hip -- forward pass of the linear line search with 32 lanes per instance (PosOrn, nb_deriv = 1)
+// ilqr_kernels_wave.hip -- the single-integrator fast path around the backward sweep (PosOrn / JointSpace, nb_deriv = 1):
+//   k_forward_wg      forward pass of the linear line search, one 8-wave workgroup per 16 instances, 32 lanes per instance
+//   k_select          line-search decision: task cost of every step size from the exported keypoint deviations (one lane per alpha)
+//   k_apply, k_flip   accepted trajectory x(alpha) = xbar + alpha (x(1) - xbar) and the AL bookkeeping in one pass; buffer flip
+//   k_init_roll_lti, k_init_finish   initial rollout with one lane per (instance, coordinate)
 //
-// k_forward_lin (ilqr_kernels_rows.hip) gives each instance 8 lanes: B = 4096 is then 512 single-wave workgroups, half of the
-// 1024 SIMDs stay empty and the other half run one wave whose per-step chain (LDS gather -> dot product -> sqrt -> dynamics)
-// is fully exposed.  Here the 7 x 8 gain record {K | d} of a step is spread over 32 lanes -- lane (r, jl) owns the two
-// adjacent entries (r, 2jl), (r, 2jl+1) and reads them with ONE 16-byte load, so a wave reads two whole records as 1 KiB
-// of contiguous memory -- and B = 4096 becomes 2048 waves, two per SIMD.  Per step and lane:
+// The forward pass.  k_forward_lin (ilqr_kernels_rows.hip) gives each instance 8 lanes: B = 4096 is then 512 single-wave
+// workgroups, half of the 1024 SIMDs stay empty and the other half run one wave whose per-step chain (LDS gather -> dot product
+// -> sqrt -> dynamics) is fully exposed.  Here the 7 x 8 gain record {K | d} of a step is spread over 32 lanes -- lane (r, jl)
+// owns the two adjacent entries (r, 2jl), (r, 2jl+1) and reads them with ONE 16-byte load, so a wave reads two whole records as
+// 1 KiB of contiguous memory -- and B = 4096 becomes 2048 waves, two per SIMD.  Per step and lane:
 //     partial = K[r][c0] dx[c0] + K[r][c1] dx[c1]          (c1 = 7 is the feed-forward column: dx[7] := 1)
 //     du[r]   = sum over the row's 4 lanes                 (two DPP quad permutes, no LDS)
 //     du[c0], du[c1] <- ds_bpermute from the rows c0, c1   (the transpose the product needs; LDS crossbar, no LDS memory)
 //     dx[c]  += dt du[c]                                    every lane keeps its two columns of the state deviation
-// The keypoint cost (FK) is not evaluated here: at keypoint steps the deviation (dx, du) is written to `kpdev`, and
-// k_select evaluates the task cost of all step sizes with one lane per (instance, alpha), picks the winner
-// (ILQRRecursive.cpp:101-155) and does the bookkeeping.  That keeps the FK call -- 256 VGPRs + scratch -- out of this kernel.
+// xbar, ubar come in and x(1), u(1) go out through LDS in blocks of 8 timesteps, loaded / stored by the whole workgroup as full
+// 128-byte lines (see k_forward_wg).  The keypoint cost (FK) is not evaluated here: at keypoint steps the deviation (dx, du) is
+// written to `kpdev`, and k_select evaluates the task cost of all step sizes with one lane per (instance, alpha), picks the
+// winner (ILQRRecursive.cpp:101-155) and does the bookkeeping.  That keeps the FK call -- 256 VGPRs + scratch -- out of the rollout.
 #include <cstdlib>
 #include <cstring>
 
