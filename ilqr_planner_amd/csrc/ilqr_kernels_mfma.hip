@@ -229,13 +229,13 @@ __global__ __launch_bounds__(64) void k_backward_mfma(Bufs a) {
                 const int q = h + 4 * t;
                 if (q < NX) {
                     const double bq = sbc[q];
-                    wT += bq * sP[q][cj];
+                    wT += bq * (colA ? sp[q] : sP[q][cj]);  // the affine column carries p: its "column sum" is bc . p
                     wA += atp(cj, q) * bq;
                 }
             }
             wT = cross_rows_sum(wT);
             wA = cross_rows_sum(wA);
-            bp = wave_sum_m(isX ? sbc[vx] * sp[vx] : 0.0);
+            bp = wT;  // meaningful on the lanes of the affine column, which are the ones that form Qu
         }
         // ---- 3. B^T P in the U-map
         double btp[2];
@@ -337,14 +337,15 @@ __global__ __launch_bounds__(64) void k_backward_mfma(Bufs a) {
         UNR for (int r = 0; r < 2; r++)
             if (uv[r] && c16 <= NX) Kout[ui[r] * ROWP + c16] = Kt[r];  // gain record row {K[i][0..NX-1], d[i]}
         Kout -= Kstep;
+        // T1~ and the Qxu K~ part of P~' depend on K~ only: two independent accumulator chains, then K~^T T1~ on top
         d4_t T1 = {qux[0], qux[1], 0, 0};
-        T1 = __builtin_amdgcn_mfma_f64_16x16x4f64(qa0, Kt[0], T1, 0, 0, 0);
-        T1 = __builtin_amdgcn_mfma_f64_16x16x4f64(qa1, Kt[1], T1, 0, 0, 0);
         d4_t Pn = {qxx[0], qxx[1], qxx[2], qxx[3]};
+        T1 = __builtin_amdgcn_mfma_f64_16x16x4f64(qa0, Kt[0], T1, 0, 0, 0);
+        Pn = __builtin_amdgcn_mfma_f64_16x16x4f64(qxu[0], Kt[0], Pn, 0, 0, 0);
+        T1 = __builtin_amdgcn_mfma_f64_16x16x4f64(qa1, Kt[1], T1, 0, 0, 0);
+        Pn = __builtin_amdgcn_mfma_f64_16x16x4f64(qxu[1], Kt[1], Pn, 0, 0, 0);
         Pn = __builtin_amdgcn_mfma_f64_16x16x4f64(Kt[0], T1[0], Pn, 0, 0, 0);
         Pn = __builtin_amdgcn_mfma_f64_16x16x4f64(Kt[1], T1[1], Pn, 0, 0, 0);
-        Pn = __builtin_amdgcn_mfma_f64_16x16x4f64(qxu[0], Kt[0], Pn, 0, 0, 0);
-        Pn = __builtin_amdgcn_mfma_f64_16x16x4f64(qxu[1], Kt[1], Pn, 0, 0, 0);
         LDS_ORDER();
         UNR for (int r = 0; r < 4; r++) *wP[r] = Pn[r];
         LDS_ORDER();
