@@ -58,7 +58,7 @@ __device__ __forceinline__ double cross_rows_sum(double v) {  // sum over lanes 
 __device__ __forceinline__ double wave_sum_m(double v) { return cross_rows_sum(row16_sum(v)); }
 
 template <class S, bool AL>
-__global__ __launch_bounds__(64) void k_backward_mfma(Bufs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_backward_mfma(Bufs a) {
     constexpr int NX = S::NX, NU = S::NU, ND = S::ND, TM = S::TM;
     constexpr int PS = 18;  // row stride of sP / sBtP (doubles): rows 16-byte aligned, starts in distinct banks
     constexpr int TS = 10;  // row stride of the NU x NU matrices
