@@ -178,6 +178,14 @@ Mat SimulationInterface::Jr() {
         for (int c = 0; c < j.cols; c++) o(r, c) = j(j.rows - nbCarDim + r, c);
     return o;
 }
+static Mat rows_of_mat(const Mat& j, int r0, int n) {
+    Mat o(n, j.cols);
+    for (int r = 0; r < n && r0 + r < j.rows; r++)
+        for (int c = 0; c < j.cols; c++) o(r, c) = j(r0 + r, c);
+    return o;
+}
+Mat SimulationInterface::Jtp() { return rows_of_mat(Jp(), 0, nbCarDim); }
+Mat SimulationInterface::Jrp() { const Mat j = Jp(); return rows_of_mat(j, j.rows - nbCarDim, nbCarDim); }
 void SimulationInterface::sendAcc(double dt, const Vec& a, bool updateKin) {  // SimulationInterface.cpp:19-26
     for (int i = 0; i < dof; i++) {
         q[i] += dt * dq[i] + dt * dt / 2 * a[i];
@@ -251,6 +259,26 @@ void KDLRobot::updateKinematics() {  // KDLRobot.cpp:83-115
             w[i] += Jac(3 + i, j) * dq[j];
         }
     }
+    // dJ/dt = sum_j dq_j dJ/dq_j of a geometric Jacobian with columns (v_i; w_i) (utils.h:70-112, KDLRobot.cpp:112):
+    //   dJ_i/dq_j = (w_j x v_i; w_j x w_i) for j < i,  (w_i x v_j; 0) for j >= i.  Host-only; no solver reads it.
+    dJac = Mat(6, dof);
+    auto cross_into = [&](int row0, int col, double s, const double* a, const double* b) {
+        dJac(row0 + 0, col) += s * (a[1] * b[2] - a[2] * b[1]);
+        dJac(row0 + 1, col) += s * (a[2] * b[0] - a[0] * b[2]);
+        dJac(row0 + 2, col) += s * (a[0] * b[1] - a[1] * b[0]);
+    };
+    for (int i = 0; i < dof; i++) {
+        const double vi[3] = {Jac(0, i), Jac(1, i), Jac(2, i)}, wi[3] = {Jac(3, i), Jac(4, i), Jac(5, i)};
+        for (int j = 0; j < dof; j++) {
+            const double vj[3] = {Jac(0, j), Jac(1, j), Jac(2, j)}, wj[3] = {Jac(3, j), Jac(4, j), Jac(5, j)};
+            if (j < i) {
+                cross_into(0, i, dq[j], wj, vi);
+                cross_into(3, i, dq[j], wj, wi);
+            } else {
+                cross_into(0, i, dq[j], wi, vj);
+            }
+        }
+    }
 }
 
 bool KDLRobot::lowerChain(ilqr_problem_desc* d) const {
@@ -315,6 +343,7 @@ void TransformedSimulationInterface::updateKinematics() {  // :31-47
     q = r_->getJointsPos();
     dq = r_->getJointsVel();
     Jac = r_->J();
+    dJac = r_->Jp();
     x = r_->getEEPosition();
     ornQuat = r_->getEEOrnQuat();
     dx = r_->getEEVelocity();
@@ -328,17 +357,20 @@ static Vec rot_t(const Mat& T, const Vec& v) {  // R^T v
         for (int j = 0; j < 3; j++) o[i] += T(j, i) * v[j];
     return o;
 }
-Mat TransformedSimulationInterface::J() {  // :53-58  blkdiag(R,R)^T J
-    Mat o(6, Jac.cols);
+static Mat rot_t_blocks(const Mat& T, const Mat& M) {  // blkdiag(R,R)^T M
+    Mat o(6, M.cols);
+    if (M.rows != 6) return o;
     for (int blk = 0; blk < 2; blk++)
         for (int i = 0; i < 3; i++)
-            for (int c = 0; c < Jac.cols; c++) {
+            for (int c = 0; c < M.cols; c++) {
                 double a = 0;
-                for (int l = 0; l < 3; l++) a += T_(l, i) * Jac(3 * blk + l, c);
+                for (int l = 0; l < 3; l++) a += T(l, i) * M(3 * blk + l, c);
                 o(3 * blk + i, c) = a;
             }
     return o;
 }
+Mat TransformedSimulationInterface::J() { return rot_t_blocks(T_, Jac); }    // :53-58
+Mat TransformedSimulationInterface::Jp() { return rot_t_blocks(T_, dJac); }  // :60-65
 Vec TransformedSimulationInterface::getEEPosition() {  // :67-69
     return rot_t(T_, Vec{x[0] - T_(0, 3), x[1] - T_(1, 3), x[2] - T_(2, 3)});
 }
@@ -578,6 +610,162 @@ Mat System::getQMatrix(bool sparse) {  // System.cpp:341-361
     return Q;
 }
 
+// ---- single-point evaluation API (System.cpp:96-312).  Host glue: the kinematics behind getFxJac() are the simulator's
+// (KDLRobot::updateKinematics = one-configuration call of the FK kernel); the solvers do not come through here.
+std::shared_ptr<Keypoint> System::getKeypoint(int k) const {  // :96-101; the map of System::init keeps the last keypoint given for a step
+    std::shared_ptr<Keypoint> hit;
+    for (auto& kp : keypoints)
+        if (kp->getTimestep() == k) hit = kp;
+    return hit;
+}
+
+Vec System::diff(const Vec& actual_state, int k) {  // :103-109
+    auto kp = getKeypoint(k);
+    if (!kp) return Vec(nb_Q_var_, 0.0);
+    return kp->diff(actual_state);
+}
+
+Vec System::diffBatch(const Vec& x) {  // :111-119: one f(x) block per keypoint, in keypoint order
+    const int n = (int)keypoints.size();
+    if ((int)x.size() != n * nb_target_var_) throw std::runtime_error("[System] diffBatch expects nb_keypoints * nb_target_var entries");
+    Vec res((size_t)n * nb_Q_var_, 0.0);
+    for (int i = 0; i < n; i++) {
+        const Vec xt(x.begin() + (size_t)i * nb_target_var_, x.begin() + (size_t)(i + 1) * nb_target_var_);
+        const Vec d = diff(xt, keypoints[i]->getTimestep());
+        std::copy(d.begin(), d.end(), res.begin() + (size_t)i * nb_Q_var_);
+    }
+    return res;
+}
+
+std::pair<Mat, Vec> System::inspectJointLimit(const Vec& xk) {  // :121-142
+    Mat L(nb_state_var_, nb_state_var_);
+    Vec q(nb_state_var_, 0.0);
+    if (limits_set_) {
+        if ((int)xk.size() != nb_state_var_) throw std::runtime_error("[System] state has the wrong size");
+        for (int i = 0; i < nb_state_var_; i++) {
+            if (joint_limits_weight_[i] == 0) continue;
+            if (xk[i] > state_max_[i]) { q[i] = state_max_[i] - xk[i]; L(i, i) = penalty_; }
+            else if (xk[i] < state_min_[i]) { q[i] = state_min_[i] - xk[i]; L(i, i) = penalty_; }
+        }
+    }
+    return std::make_pair(L, q);
+}
+
+System::StepLimitsOut System::forwardPassWithLimits(const Vec& xk, const Vec& uk, int k) {  // :144-161: the limits look at the state given, not the new one
+    auto s = forwardPass(xk, uk, k);
+    auto Lq = inspectJointLimit(xk);
+    return std::make_tuple(std::get<0>(s), std::get<1>(s), Lq.second, Vec(nb_ctrl_var_, 0.0), std::get<2>(s), std::get<3>(s), std::get<4>(s), Lq.first);
+}
+
+std::tuple<Vec, Mat> System::getFxJac(const Vec& xk) {  // :163-179: evaluate at xk, then put the simulator back
+    const int dof = r->getDOF();
+    if ((int)xk.size() < nb_deriv_ * dof) throw std::runtime_error("[System] state has the wrong size");
+    const Vec qk(xk.begin(), xk.begin() + dof);
+    const Vec dqk = nb_deriv_ == 2 ? Vec(xk.begin() + dof, xk.begin() + 2 * dof) : Vec(dof, 0.0);
+    const Vec old_q = r->getJointsPos(), old_dq = r->getJointsVel();
+    r->setConfiguration(qk, dqk);
+    auto out = getFxJac();
+    r->setConfiguration(old_q, old_dq);
+    return out;
+}
+
+// getFxJac(xk) of the two time systems (PosOrnTimePlannerSys.cpp:114-136, JointSpaceTimePlannerSys.cpp:88-110): the last state is the clock
+static std::tuple<Vec, Mat> fx_jac_at_time_state(System& s, const Vec& xk) {
+    auto r = s.robot();
+    const int dof = r->getDOF();
+    if ((int)xk.size() != s.getNbStateVar()) throw std::runtime_error("[System] state has the wrong size");
+    const Vec qk(xk.begin(), xk.begin() + dof);
+    const Vec dqk = s.getNbDeriv() == 2 ? Vec(xk.begin() + dof, xk.begin() + 2 * dof) : Vec(dof, 0.0);
+    const Vec old_q = r->getJointsPos(), old_dq = r->getJointsVel();
+    const double old_t = r->getTime();
+    r->setConfiguration(qk, dqk);
+    r->setTime(xk.back());
+    auto out = s.getFxJac();
+    r->setConfiguration(old_q, old_dq);
+    r->setTime(old_t);
+    return out;
+}
+
+std::tuple<Vec, Vec, std::vector<std::tuple<Mat, Mat, Mat, Mat>>> System::fpBatch(const Vec& u) {  // :181-211
+    reset();
+    if (u.size() % nb_ctrl_var_) throw std::runtime_error("[System] fpBatch expects (horizon - 1) * nb_ctrl_var controls");
+    const int T = (int)u.size() / nb_ctrl_var_ + 1;
+    Vec fX((size_t)T * nb_target_var_, 0.0), qL((size_t)T * nb_state_var_, 0.0);
+    std::vector<std::tuple<Mat, Mat, Mat, Mat>> ABJL;
+    auto fJ0 = getFxJac();
+    std::copy(std::get<0>(fJ0).begin(), std::get<0>(fJ0).end(), fX.begin());
+    ABJL.push_back(std::make_tuple(Mat::Identity(nb_state_var_), Mat(nb_state_var_, nb_ctrl_var_), std::get<1>(fJ0), Mat(nb_state_var_, nb_state_var_)));
+    for (int i = 0; i < T - 1; i++) {
+        const Vec ut(u.begin() + (size_t)i * nb_ctrl_var_, u.begin() + (size_t)(i + 1) * nb_ctrl_var_);
+        auto o = forwardPassWithLimits(getState(), ut, i + 1);
+        std::copy(std::get<1>(o).begin(), std::get<1>(o).end(), fX.begin() + (size_t)(i + 1) * nb_target_var_);
+        std::copy(std::get<2>(o).begin(), std::get<2>(o).end(), qL.begin() + (size_t)(i + 1) * nb_state_var_);
+        ABJL.push_back(std::make_tuple(std::get<4>(o), std::get<5>(o), std::get<6>(o), std::get<7>(o)));
+    }
+    return std::make_tuple(fX, qL, ABJL);
+}
+
+Vec System::cost(const Vec& xk, const Vec& uk, int k) {  // :213-234: the control term only counts at keypoint steps
+    double c = 0;
+    if (auto kp = getKeypoint(k)) {
+        const Vec fx = std::get<0>(getFxJac(xk));
+        const Vec e = kp->diff(fx);
+        const Mat Q = kp->getPrecision();
+        for (int i = 0; i < Q.rows; i++)
+            for (int j = 0; j < Q.cols; j++) c += e[i] * Q(i, j) * e[j];
+        for (size_t i = 0; i < uk.size() && i < Rdiag.size(); i++) c += uk[i] * Rdiag[i] * uk[i];
+    }
+    if (limits_set_) {
+        auto Lq = inspectJointLimit(xk);
+        for (int i = 0; i < nb_state_var_; i++) c += Lq.second[i] * Lq.first(i, i) * Lq.second[i];
+    }
+    return Vec(1, c);
+}
+
+Vec System::cost_x(const Vec& xk, const Vec&, int k) {  // :248-272
+    Vec g(nb_state_var_, 0.0);
+    if (auto kp = getKeypoint(k)) {
+        auto fJ = getFxJac(xk);
+        const Mat& J = std::get<1>(fJ);
+        const Vec e = kp->diff(std::get<0>(fJ));
+        const Mat Q = kp->getPrecision();
+        Vec Qe(Q.rows, 0.0);
+        for (int i = 0; i < Q.rows; i++)
+            for (int j = 0; j < Q.cols; j++) Qe[i] += Q(i, j) * e[j];
+        for (int a = 0; a < J.cols && a < nb_state_var_; a++)
+            for (int i = 0; i < J.rows; i++) g[a] -= J(i, a) * Qe[i];
+    }
+    if (limits_set_) {
+        auto Lq = inspectJointLimit(xk);
+        for (int i = 0; i < nb_state_var_; i++) g[i] -= Lq.first(i, i) * Lq.second[i];
+    }
+    return g;
+}
+
+Mat System::cost_xx(const Vec& xk, const Vec&, int k) {  // :286-308
+    Mat H(nb_state_var_, nb_state_var_);
+    if (auto kp = getKeypoint(k)) {
+        const Mat J = std::get<1>(getFxJac(xk));
+        const Mat Q = kp->getPrecision();
+        Mat QJ(Q.rows, J.cols);
+        for (int i = 0; i < Q.rows; i++)
+            for (int j = 0; j < Q.cols; j++)
+                if (Q(i, j) != 0.0)
+                    for (int a = 0; a < J.cols; a++) QJ(i, a) += Q(i, j) * J(j, a);
+        for (int a = 0; a < J.cols && a < nb_state_var_; a++)
+            for (int b = 0; b < J.cols && b < nb_state_var_; b++) {
+                double v = 0;
+                for (int i = 0; i < J.rows; i++) v += J(i, a) * QJ(i, b);
+                H(a, b) += v;
+            }
+    }
+    if (limits_set_) {
+        auto Lq = inspectJointLimit(xk);
+        for (int i = 0; i < nb_state_var_; i++) H(i, i) += Lq.first(i, i) * Lq.first(i, i);
+    }
+    return H;
+}
+
 void System::lower(ilqr_problem_desc* d) const {
     ilqr_desc_defaults(d);
     if (!r->lowerChain(d)) {
@@ -652,6 +840,104 @@ SequentialSystem::SequentialSystem(const std::shared_ptr<sim::SimulationInterfac
 }
 void SequentialSystem::reset() {
     for (auto& sy : systems_) sy->reset();
+}
+// ---- SequentialSystem evaluation (SequentialSystem.cpp:78-274)
+System::StepOut SequentialSystem::forwardPass(const Vec& xk, const Vec& uk, int k) {  // :78-91
+    auto o = systems_[0]->forwardPass(xk, uk, k);
+    for (size_t i = 1; i < systems_.size(); i++) systems_[i]->robot()->updateKinematics();
+    auto fJ = getFxJac();
+    return std::make_tuple(std::get<0>(o), std::get<0>(fJ), std::get<2>(o), std::get<3>(o), std::get<1>(fJ));
+}
+std::tuple<Vec, Mat> SequentialSystem::getFxJac() {  // :93-113: f(x) and J of the sub-systems stacked
+    Vec fx;
+    Mat J(nb_Q_var_, nb_state_var_);
+    int row = 0;
+    for (auto& sy : systems_) {
+        auto fJ = sy->getFxJac();
+        const Mat& Jk = std::get<1>(fJ);
+        fx.insert(fx.end(), std::get<0>(fJ).begin(), std::get<0>(fJ).end());
+        for (int i = 0; i < Jk.rows; i++)
+            for (int j = 0; j < Jk.cols; j++) J(row + i, j) = Jk(i, j);
+        row += Jk.rows;
+    }
+    return std::make_tuple(fx, J);
+}
+Vec SequentialSystem::diff(const Vec& state, int k) {
+    Vec out;
+    size_t o = 0;
+    for (auto& sy : systems_) {
+        const Vec part(state.begin() + o, state.begin() + o + sy->getNbTargetVar());
+        const Vec d = sy->diff(part, k);
+        out.insert(out.end(), d.begin(), d.end());
+        o += sy->getNbTargetVar();
+    }
+    return out;
+}
+static void add_to(Vec& a, const Vec& b) { for (size_t i = 0; i < a.size(); i++) a[i] += b[i]; }
+static void add_to(Mat& a, const Mat& b) { for (size_t i = 0; i < a.d.size(); i++) a.d[i] += b.d[i]; }
+Vec SequentialSystem::cost(const Vec& xk, const Vec& uk, int k) { Vec c(1, 0.0); for (auto& sy : systems_) add_to(c, sy->cost(xk, uk, k)); return c; }
+Vec SequentialSystem::cost_x(const Vec& xk, const Vec& uk, int k) { Vec c(nb_state_var_, 0.0); for (auto& sy : systems_) add_to(c, sy->cost_x(xk, uk, k)); return c; }
+Mat SequentialSystem::cost_xx(const Vec& xk, const Vec& uk, int k) { Mat c(nb_state_var_, nb_state_var_); for (auto& sy : systems_) add_to(c, sy->cost_xx(xk, uk, k)); return c; }
+Vec SequentialSystem::cost_F(const Vec& xk) { Vec c(1, 0.0); for (auto& sy : systems_) add_to(c, sy->cost_F(xk)); return c; }
+Vec SequentialSystem::cost_F_x(const Vec& xk) { Vec c(nb_state_var_, 0.0); for (auto& sy : systems_) add_to(c, sy->cost_F_x(xk)); return c; }
+Mat SequentialSystem::cost_F_xx(const Vec& xk) { Mat c(nb_state_var_, nb_state_var_); for (auto& sy : systems_) add_to(c, sy->cost_F_xx(xk)); return c; }
+
+Vec SequentialSystem::getMuVector(bool sparse) {
+    const int nt = nb_target_var_;
+    if (!sparse) {
+        Vec mu((size_t)horizon_ * nt, 0.0);
+        int idx = 0;
+        for (auto& sy : systems_) {
+            const Vec mk = sy->getMuVector(false);
+            const int ntk = sy->getNbTargetVar();
+            for (int j = 0; j < horizon_; j++) std::copy(mk.begin() + (size_t)j * ntk, mk.begin() + (size_t)(j + 1) * ntk, mu.begin() + (size_t)j * nt + idx);
+            idx += ntk;
+        }
+        return mu;
+    }
+    Vec mu((size_t)nt * keypoints.size(), 0.0);
+    for (size_t i = 0; i < keypoints.size(); i++) {
+        int idx = 0;
+        for (auto& sy : systems_) {
+            if (auto kp = sy->getKeypoint(keypoints[i]->getTimestep())) {
+                const Vec st = kp->getState();
+                std::copy(st.begin(), st.end(), mu.begin() + i * nt + idx);
+            }
+            idx += sy->getNbTargetVar();
+        }
+    }
+    return mu;
+}
+Mat SequentialSystem::getQMatrix(bool sparse) {
+    const int nq = nb_Q_var_;
+    if (!sparse) {
+        Mat Q(horizon_ * nq, horizon_ * nq);
+        int idx = 0;
+        for (auto& sy : systems_) {
+            const Mat Qk = sy->getQMatrix(false);
+            const int nk = sy->getNbQVar();
+            for (int j = 0; j < horizon_; j++)
+                for (int a = 0; a < nk; a++)
+                    for (int b = 0; b < nk; b++) Q(j * nq + idx + a, j * nq + idx + b) = Qk(j * nk + a, j * nk + b);
+            idx += nk;
+        }
+        return Q;
+    }
+    const int n = (int)keypoints.size();
+    Mat Q(n * nq, n * nq);
+    for (int i = 0; i < n; i++) {
+        int idx = 0;
+        for (auto& sy : systems_) {
+            const int nk = sy->getNbQVar();
+            if (auto kp = sy->getKeypoint(keypoints[i]->getTimestep())) {
+                const Mat P = kp->getPrecision();
+                for (int a = 0; a < nk; a++)
+                    for (int b = 0; b < nk; b++) Q(i * nq + idx + a, i * nq + idx + b) = P(a, b);
+            }
+            idx += nk;
+        }
+    }
+    return Q;
 }
 // Device form: dynamics, chain and limits of the first sub-system; every keypoint keeps the frame and the control penalty of
 // its own sub-system; the limit terms count once per sub-system (SequentialSystem.cpp:144-168 sums cost, cost_x, cost_xx).
@@ -736,6 +1022,73 @@ Vec PosOrnPlannerSys::getState() {
 }
 void PosOrnPlannerSys::reset() { r->setConfiguration(q0_, dq0_); }
 
+static void set_block(Mat& M, int r0, int c0, const Mat& S) {
+    for (int i = 0; i < S.rows; i++)
+        for (int j = 0; j < S.cols; j++) M(r0 + i, c0 + j) = S(i, j);
+}
+static void append_v(Vec& o, const Vec& a) { o.insert(o.end(), a.begin(), a.end()); }
+
+std::tuple<Vec, Mat> PosOrnPlannerSys::getFxJac() {  // PosOrnPlannerSys.cpp:80-102
+    Vec fx = r->getEEPosition();
+    append_v(fx, r->getEEOrnQuat());
+    const Mat Jk = r->J();
+    if (nb_deriv_ == 1) return std::make_tuple(fx, Jk);
+    append_v(fx, r->getEEVelocity());
+    append_v(fx, r->getEEAngVelQuat());
+    Mat J(2 * Jk.rows, 2 * Jk.cols);
+    set_block(J, 0, 0, Jk);
+    set_block(J, Jk.rows, Jk.cols, Jk);
+    return std::make_tuple(fx, J);
+}
+// constant-dt dynamics shared by PosOrnPlannerSys and JointSpacePlannerSys (PosOrnPlannerSys.cpp:114-138, JointSpacePlannerSys.cpp:93-116)
+static void step_fixed_dt(sim::SimulationInterface& r, int nb_deriv, double dt, const Vec& uk, Mat& A, Mat& B) {
+    const int dof = r.getDOF();
+    if ((int)uk.size() != dof) throw std::runtime_error("[System] control has the wrong size");
+    const int nx = nb_deriv * dof;
+    A = Mat::Identity(nx);
+    B = Mat(nx, dof);
+    if (nb_deriv == 1) {
+        for (int i = 0; i < dof; i++) B(i, i) = dt;
+        r.sendVel(dt, uk);
+    } else {
+        for (int i = 0; i < dof; i++) { A(i, dof + i) = dt; B(i, i) = dt * dt / 2; B(dof + i, i) = dt; }
+        r.sendAcc(dt, uk);
+    }
+}
+// dt = u_last^2 dynamics shared by the two time systems (PosOrnTimePlannerSys.cpp:149-185, JointSpaceTimePlannerSys.cpp:123-155);
+// the 2nd-order time column uses the velocity AFTER the step, as upstream does
+static void step_time(sim::SimulationInterface& r, int nb_deriv, const Vec& uk, Mat& A, Mat& B) {
+    const int dof = r.getDOF();
+    if ((int)uk.size() != dof + 1) throw std::runtime_error("[System] control has the wrong size");
+    const int nx = nb_deriv * dof + 1, nu = dof + 1;
+    const double ds = uk[nu - 1], dt = ds * ds;
+    const Vec v(uk.begin(), uk.begin() + dof);
+    A = Mat::Identity(nx);
+    B = Mat(nx, nu);
+    if (nb_deriv == 1) {
+        r.sendVel(dt, v);
+        for (int i = 0; i < dof; i++) { B(i, i) = dt; B(i, nu - 1) = 2 * ds * v[i]; }
+        B(nx - 1, nu - 1) = 2 * ds;
+    } else {
+        r.sendAcc(dt, v);
+        const Vec dq = r.getJointsVel();
+        for (int i = 0; i < dof; i++) {
+            A(i, dof + i) = dt;
+            B(i, i) = dt * dt / 2;
+            B(dof + i, i) = dt;
+            B(i, nu - 1) = 2 * ds * dq[i] + 2 * ds * ds * ds * v[i];
+            B(dof + i, nu - 1) = 2 * ds * v[i];
+        }
+        B(nx - 1, nu - 1) = 2 * ds;
+    }
+}
+System::StepOut PosOrnPlannerSys::forwardPass(const Vec&, const Vec& uk, int) {
+    Mat A, B;
+    step_fixed_dt(*r, nb_deriv_, dt_, uk, A, B);
+    auto fJ = getFxJac();
+    return std::make_tuple(getState(), std::get<0>(fJ), A, B, std::get<1>(fJ));
+}
+
 // A joint-space descriptor of n < 7 joints widened to the 7 the device kernels are built for: the extra joints get zero precision,
 // zero limit weight and the first joint's control penalty; with u = 0 they stay at rest, so the n-joint problem is unchanged.
 static void pad_joint_desc(ilqr_problem_desc* d, int n, int tm) {
@@ -801,6 +1154,18 @@ Vec JointSpacePlannerSys::getState() {
     return xk;
 }
 void JointSpacePlannerSys::reset() { r->setConfiguration(q0_, dq0_); }
+
+std::tuple<Vec, Mat> JointSpacePlannerSys::getFxJac() {  // JointSpacePlannerSys.cpp:77-81 (nb_Q_var x nb_ctrl_var identity, as upstream)
+    Mat J(nb_Q_var_, nb_ctrl_var_);
+    for (int i = 0; i < std::min(nb_Q_var_, nb_ctrl_var_); i++) J(i, i) = 1;
+    return std::make_tuple(getState(), J);
+}
+System::StepOut JointSpacePlannerSys::forwardPass(const Vec&, const Vec& uk, int) {
+    Mat A, B;
+    step_fixed_dt(*r, nb_deriv_, dt_, uk, A, B);
+    auto fJ = getFxJac();
+    return std::make_tuple(getState(), std::get<0>(fJ), A, B, std::get<1>(fJ));
+}
 void JointSpacePlannerSys::lower(ilqr_problem_desc* d) const {
     if (nb_deriv_ != 1) throw std::runtime_error("[ilqr_hip] JointSpacePlannerSys is lowered for nbDeriv = 1 only (the 2nd-order variant is inconsistent upstream)");
     if (r->getDOF() > 7) throw std::runtime_error("[ilqr_hip] joint-space systems are lowered for at most 7 joints");
@@ -853,6 +1218,19 @@ Vec JointSpaceTimePlannerSys::getState() {
     return xk;
 }
 void JointSpaceTimePlannerSys::reset() { r->setConfiguration(q0_, dq0_); }
+
+std::tuple<Vec, Mat> JointSpaceTimePlannerSys::getFxJac() {  // JointSpaceTimePlannerSys.cpp:82-86
+    Mat J(nb_target_var_, nb_ctrl_var_);
+    for (int i = 0; i < std::min(nb_target_var_, nb_ctrl_var_); i++) J(i, i) = 1;
+    return std::make_tuple(getState(), J);
+}
+std::tuple<Vec, Mat> JointSpaceTimePlannerSys::getFxJac(const Vec& xk) { return fx_jac_at_time_state(*this, xk); }
+System::StepOut JointSpaceTimePlannerSys::forwardPass(const Vec&, const Vec& uk, int) {
+    Mat A, B;
+    step_time(*r, nb_deriv_, uk, A, B);
+    auto fJ = getFxJac();
+    return std::make_tuple(getState(), std::get<0>(fJ), A, B, std::get<1>(fJ));
+}
 void JointSpaceTimePlannerSys::lower(ilqr_problem_desc* d) const {
     if (nb_deriv_ != 1) throw std::runtime_error("[ilqr_hip] JointSpaceTimePlannerSys is lowered for nbDeriv = 1 only");
     if (r->getDOF() > 7) throw std::runtime_error("[ilqr_hip] joint-space systems are lowered for at most 7 joints");
@@ -901,6 +1279,34 @@ Vec PosOrnTimePlannerSys::getState() {
     return xk;
 }
 void PosOrnTimePlannerSys::reset() { r->setConfiguration(q0_, dq0_); }
+
+std::tuple<Vec, Mat> PosOrnTimePlannerSys::getFxJac() {  // PosOrnTimePlannerSys.cpp:85-112
+    Vec fx = r->getEEPosition();
+    append_v(fx, r->getEEOrnQuat());
+    const Mat J = r->J();
+    if (nb_deriv_ == 1) {
+        fx.push_back(r->getTime());
+        Mat Jk(J.rows + 1, J.cols + 1);
+        set_block(Jk, 0, 0, J);
+        Jk(J.rows, J.cols) = 1;
+        return std::make_tuple(fx, Jk);
+    }
+    append_v(fx, r->getEEVelocity());
+    append_v(fx, r->getEEAngVelQuat());
+    fx.push_back(r->getTime());
+    Mat Js(2 * J.rows + 1, 2 * J.cols + 1);
+    set_block(Js, 0, 0, J);
+    set_block(Js, J.rows, J.cols, J);
+    Js(2 * J.rows, 2 * J.cols) = 1;
+    return std::make_tuple(fx, Js);
+}
+std::tuple<Vec, Mat> PosOrnTimePlannerSys::getFxJac(const Vec& xk) { return fx_jac_at_time_state(*this, xk); }
+System::StepOut PosOrnTimePlannerSys::forwardPass(const Vec&, const Vec& uk, int) {
+    Mat A, B;
+    step_time(*r, nb_deriv_, uk, A, B);
+    auto fJ = getFxJac();
+    return std::make_tuple(getState(), std::get<0>(fJ), A, B, std::get<1>(fJ));
+}
 }  // namespace sys
 
 // ------------------------------------------------------------------------------------------------ solvers

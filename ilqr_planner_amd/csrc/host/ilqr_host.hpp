@@ -8,9 +8,8 @@
 //   primitives, Sd, CallBackMessage                   include/ilqr_planner/utils/*.h
 // No Eigen (absent from this image): Vec/Mat are plain row-major containers.  These classes hold state and LOWER it to
 // the POD descriptor of include/ilqr_hip.h; every solve and every kinematics evaluation runs on the GPU through that C
-// ABI -- there is no host solver.  What is NOT mirrored: the System virtuals the reference's own CPU loops call
-// (forwardPass, cost*, getFxJac, fpBatch), Robot2D, TransformedSimulationInterface, SequentialSystem, JointSpace*,
-// BatchILQR (no PSI), LQT -- see DESIGN.md.
+// ABI -- there is no host solver.  The single-point System API (forwardPass, cost*, getFxJac, fpBatch ...) is host glue over
+// the simulator for users who call it directly; the solvers never use it.  NOT mirrored: BatchILQR (no PSI), LQT -- see DESIGN.md.
 #pragma once
 
 #include <memory>
@@ -65,6 +64,9 @@ public:
     Mat Jt();
     Mat Jr();
     virtual Mat J() { return Jac; }
+    Mat Jtp();  // rows of Jp(), SimulationInterface.cpp:41-47
+    Mat Jrp();
+    virtual Mat Jp() { return dJac; }  // dJ/dt (:53-55)
     Mat dQuatToDxJac(const Vec& quat) { return Sd::dQuatToDxJac(quat); }
     virtual void sendAcc(double dt, const Vec& ddq, bool updateKin = true);
     virtual void sendVel(double dt, const Vec& dq, bool updateKin = true);
@@ -87,7 +89,7 @@ public:
 
 protected:
     Vec q, dq, ddq, x, dx, ornQuat, w;
-    Mat Jac;
+    Mat Jac, dJac;
     int dof = 0, nbCarDim = 3;
     double t = 0;
 };
@@ -130,6 +132,7 @@ public:
     TransformedSimulationInterface(const std::shared_ptr<SimulationInterface>& r, const Mat& T);
     void updateKinematics() override;
     Mat J() override;
+    Mat Jp() override;
     Vec getEEPosition() override;
     Vec getEEVelocity() override;
     Vec getEEAngVel() override;
@@ -250,8 +253,8 @@ public:
     System(const std::shared_ptr<sim::SimulationInterface>& r, const std::vector<std::shared_ptr<Keypoint>>& keypoints, const Vec& RtDiag,
            int horizon, int nb_deriv, const std::vector<std::string>& tags);
     virtual ~System() {}
-    Vec getMuVector(bool sparse);
-    Mat getQMatrix(bool sparse);
+    virtual Vec getMuVector(bool sparse);
+    virtual Mat getQMatrix(bool sparse);
     Mat getRt();
     int getNbStateVar() { return nb_state_var_; }
     int getNbCtrlVar() { return nb_ctrl_var_; }
@@ -263,6 +266,29 @@ public:
     Vec getInitFoXState() { return f_x0_; }
     virtual Vec getState() = 0;
     virtual void reset() = 0;
+    // ---- single-point evaluation API of System.h:66-194 (host glue over the simulator, whose kinematics run on the device).
+    // The solvers never call these: they lower the system and run the batched kernels.
+    typedef std::tuple<Vec, Vec, Mat, Mat, Mat> StepOut;                          // x, f(x), A, B, J
+    typedef std::tuple<Vec, Vec, Vec, Vec, Mat, Mat, Mat, Mat> StepLimitsOut;     // x, f(x), q, u, A, B, J, L
+    virtual StepOut forwardPass(const Vec& xk, const Vec& uk, int k) = 0;         // advances the simulator (xk is ignored as upstream)
+    virtual std::tuple<Vec, Mat> getFxJac() = 0;
+    virtual std::tuple<Vec, Mat> getFxJac(const Vec& xk);                         // System.cpp:163-179
+    virtual Vec diff(const Vec& actual_state, int k);                             // :103-109
+    Vec diffBatch(const Vec& x);                                                  // :111-119
+    std::pair<Mat, Vec> inspectJointLimit(const Vec& xk);                         // :121-142
+    StepLimitsOut forwardPassWithLimits(const Vec& xk, const Vec& uk, int k);     // :144-161
+    std::tuple<Vec, Vec, std::vector<std::tuple<Mat, Mat, Mat, Mat>>> fpBatch(const Vec& u);  // :181-211
+    virtual Vec cost(const Vec& xk, const Vec& uk, int k);                        // :213-234
+    virtual Vec cost_x(const Vec& xk, const Vec& uk, int k);                      // :248-272
+    virtual Mat cost_xx(const Vec& xk, const Vec& uk, int k);                     // :286-308
+    Vec cost_u(const Vec&, const Vec& uk, int) { Vec o(uk.size()); for (size_t i = 0; i < uk.size(); i++) o[i] = Rdiag[i] * uk[i]; return o; }
+    Mat cost_uu(const Vec&, const Vec&, int) { return getRt(); }
+    Mat cost_ux(const Vec&, const Vec& uk, int) { return Mat((int)uk.size(), nb_state_var_); }
+    Mat cost_xu(const Vec&, const Vec& uk, int) { return Mat(nb_state_var_, (int)uk.size()); }
+    virtual Vec cost_F(const Vec& xk) { return cost(xk, Vec(nb_ctrl_var_, 0.0), horizon_ - 1); }
+    virtual Vec cost_F_x(const Vec& xk) { return cost_x(xk, Vec(nb_ctrl_var_, 0.0), horizon_ - 1); }
+    virtual Mat cost_F_xx(const Vec& xk) { return cost_xx(xk, Vec(nb_ctrl_var_, 0.0), horizon_ - 1); }
+    std::shared_ptr<Keypoint> getKeypoint(int k) const;                           // :96-101 (the last of duplicates wins, as in the map)
     std::shared_ptr<sim::SimulationInterface> robot() { return r; }
     const std::vector<std::shared_ptr<Keypoint>>& getKeypoints() const { return keypoints; }
     // Lowering to the C ABI's POD descriptor.  Throws for systems the device cannot run.
@@ -304,6 +330,9 @@ public:
                      int horizon, int nb_deriv, double dt);
     Vec getState() override;
     void reset() override;
+    StepOut forwardPass(const Vec& xk, const Vec& uk, int k) override;
+    std::tuple<Vec, Mat> getFxJac() override;
+    using System::getFxJac;
 
 protected:
     void localInit(double dt);
@@ -321,6 +350,9 @@ public:
                          int horizon, int nb_deriv, double dt);
     Vec getState() override;
     void reset() override;
+    StepOut forwardPass(const Vec& xk, const Vec& uk, int k) override;
+    std::tuple<Vec, Mat> getFxJac() override;
+    using System::getFxJac;
     void lower(ilqr_problem_desc* d) const override;
     int paddedFromDof() const override { return r->getDOF() < 7 ? r->getDOF() : 0; }
 
@@ -339,6 +371,9 @@ public:
                              int horizon, int nb_deriv);
     Vec getState() override;
     void reset() override;
+    StepOut forwardPass(const Vec& xk, const Vec& uk, int k) override;
+    std::tuple<Vec, Mat> getFxJac() override;
+    std::tuple<Vec, Mat> getFxJac(const Vec& xk) override;
     void lower(ilqr_problem_desc* d) const override;
     int paddedFromDof() const override { return r->getDOF() < 7 ? r->getDOF() : 0; }
 
@@ -356,6 +391,9 @@ public:
                          int horizon, int nb_deriv);
     Vec getState() override;
     void reset() override;
+    StepOut forwardPass(const Vec& xk, const Vec& uk, int k) override;
+    std::tuple<Vec, Mat> getFxJac() override;
+    std::tuple<Vec, Mat> getFxJac(const Vec& xk) override;
 
 protected:
     void localInit();
@@ -368,6 +406,18 @@ public:
                      int horizon, int nb_deriv);
     Vec getState() override { return systems_.at(0)->getState(); }
     void reset() override;
+    StepOut forwardPass(const Vec& xk, const Vec& uk, int k) override;
+    std::tuple<Vec, Mat> getFxJac() override;
+    using System::getFxJac;
+    Vec diff(const Vec& state, int k) override;                       // SequentialSystem.cpp:167-183
+    Vec cost(const Vec& xk, const Vec& uk, int k) override;           // :143-149 (sums of the sub-systems, as are the five below)
+    Vec cost_x(const Vec& xk, const Vec& uk, int k) override;
+    Mat cost_xx(const Vec& xk, const Vec& uk, int k) override;
+    Vec cost_F(const Vec& xk) override;
+    Vec cost_F_x(const Vec& xk) override;
+    Mat cost_F_xx(const Vec& xk) override;
+    Vec getMuVector(bool sparse) override;                            // :185-226
+    Mat getQMatrix(bool sparse) override;                             // :228-274 (block diagonals of the sub-systems)
     void lower(ilqr_problem_desc* d) const override;
     const std::vector<std::shared_ptr<System>>& systems() const { return systems_; }
 

@@ -104,6 +104,9 @@ PYBIND11_MODULE(PyLQR, m) {
         .def("Jt", &sim::SimulationInterface::Jt)
         .def("Jr", &sim::SimulationInterface::Jr)
         .def("J", &sim::SimulationInterface::J)
+        .def("Jtp", &sim::SimulationInterface::Jtp)
+        .def("Jrp", &sim::SimulationInterface::Jrp)
+        .def("Jp", &sim::SimulationInterface::Jp)
         .def("get_ee_pos", &sim::SimulationInterface::getEEPosition)
         .def("get_ee_orn", &sim::SimulationInterface::getEEOrnQuat)
         .def("get_ee_vel", &sim::SimulationInterface::getEEVelocity)
@@ -173,8 +176,26 @@ PYBIND11_MODULE(PyLQR, m) {
              py::arg("orientation"), py::arg("dorientation"), py::arg("precision"), py::arg("continuous_time"), py::arg("timestep"))
         .def("get_continuous_time", &sys::SpacetimeKeypoint::getContinuousTime);
     py::class_<sys::System, std::shared_ptr<sys::System>>(m_sys, "System")
-        .def("get_mu_vector", &sys::System::getMuVector)
-        .def("get_Q_matrix", &sys::System::getQMatrix)
+        .def("get_mu_vector", &sys::System::getMuVector, py::arg("sparse") = false)
+        .def("get_Q_matrix", &sys::System::getQMatrix, py::arg("sparse") = false)
+        // single-point evaluation API (bindings.cpp:414-497); host glue, the solvers run the batched device path instead
+        .def("forward_pass", &sys::System::forwardPass, py::arg("xk"), py::arg("uk"), py::arg("k"))
+        .def("diff", &sys::System::diff, py::arg("actual_state"), py::arg("k"))
+        .def("diff_batch", &sys::System::diffBatch, py::arg("x"))
+        .def("forward_pass_with_limits", &sys::System::forwardPassWithLimits, py::arg("xk"), py::arg("uk"), py::arg("k"))
+        .def("forward_pass_batch", &sys::System::fpBatch, py::arg("u"))
+        .def("cost_F", &sys::System::cost_F, py::arg("xk"))
+        .def("cost_F_x", &sys::System::cost_F_x, py::arg("xk"))
+        .def("cost_F_xx", &sys::System::cost_F_xx, py::arg("xk"))
+        .def("cost", &sys::System::cost, py::arg("xk"), py::arg("uk"), py::arg("k"))
+        .def("cost_x", &sys::System::cost_x, py::arg("xk"), py::arg("uk"), py::arg("k"))
+        .def("cost_xx", &sys::System::cost_xx, py::arg("xk"), py::arg("uk"), py::arg("k"))
+        .def("cost_u", &sys::System::cost_u, py::arg("xk"), py::arg("uk"), py::arg("k"))
+        .def("cost_uu", &sys::System::cost_uu, py::arg("xk"), py::arg("uk"), py::arg("k"))
+        .def("cost_xu", &sys::System::cost_xu, py::arg("xk"), py::arg("uk"), py::arg("k"))
+        .def("cost_ux", &sys::System::cost_ux, py::arg("xk"), py::arg("uk"), py::arg("k"))
+        .def("get_fx_jac", static_cast<std::tuple<Vec, Mat> (sys::System::*)()>(&sys::System::getFxJac))
+        .def("get_fx_jac", static_cast<std::tuple<Vec, Mat> (sys::System::*)(const Vec&)>(&sys::System::getFxJac), py::arg("xk"))
         .def("get_nb_state_var", &sys::System::getNbStateVar)
         .def("get_nb_ctrl_var", &sys::System::getNbCtrlVar)
         .def("get_nb_target_var", &sys::System::getNbTargetVar)
