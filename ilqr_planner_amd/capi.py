@@ -24,7 +24,7 @@ EXPORTS = [
     "ilqr_ctx_synchronize", "ilqr_version", "ilqr_problem_create", "ilqr_problem_destroy", "ilqr_problem_set_init_state",
     "ilqr_problem_set_keypoint_targets", "ilqr_problem_set_controls", "ilqr_problem_set_constraints",
     "ilqr_problem_set_init_state_dev", "ilqr_problem_set_keypoint_targets_dev", "ilqr_problem_set_controls_dev",
-    "ilqr_solve_recursive", "ilqr_solve_al", "ilqr_solve_batch_cp", "ilqr_problem_get_X", "ilqr_problem_get_fX",
+    "ilqr_solve_recursive", "ilqr_solve_al", "ilqr_solve_batch_cp", "ilqr_solve_batch", "ilqr_problem_get_X", "ilqr_problem_get_fX",
     "ilqr_problem_get_U", "ilqr_problem_get_K", "ilqr_problem_get_d", "ilqr_problem_get_cost", "ilqr_problem_get_alpha",
     "ilqr_problem_get_iters", "ilqr_problem_get_status", "ilqr_problem_get_lambda", "ilqr_problem_get_trace",
     "ilqr_problem_get_X_dev", "ilqr_problem_get_U_dev", "ilqr_problem_get_cost_dev", "ilqr_fk_batch",
@@ -116,6 +116,7 @@ def load():
     L.ilqr_solve_recursive.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.ilqr_solve_al.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int]
     L.ilqr_solve_batch_cp.argtypes = [vp, dp, C.c_int, C.c_int, C.c_int]
+    L.ilqr_solve_batch.argtypes = [vp, C.c_int, C.c_int]
     for n in ("X", "fX", "U", "K", "d", "cost", "alpha", "lambda", "X_dev", "U_dev", "cost_dev"):
         getattr(L, "ilqr_problem_get_" + n).argtypes = [vp, vp]
     L.ilqr_problem_get_iters.argtypes = [vp, ip]
@@ -329,6 +330,10 @@ class BatchProblem:
         psi = _f64(psi)
         assert psi.shape[0] == (self.T - 1) * self.dims.n_u
         self.ctx.check(self.L.ilqr_solve_batch_cp(self.h, _dp(psi), psi.shape[1], nb_iter, int(early_stop)))
+
+    def solve_batch(self, nb_iter, early_stop=True):
+        """BatchILQR::solve: the batch solver on the full control sequence (identity basis)."""
+        self.ctx.check(self.L.ilqr_solve_batch(self.h, nb_iter, int(early_stop)))
 
     # ---- results
     def _get(self, name, shape):

@@ -1581,24 +1581,49 @@ std::tuple<std::vector<Vec>, std::vector<Vec>, std::vector<Vec>> AL_ILQR::solve(
 BatchILQRCP::BatchILQRCP(const std::shared_ptr<sys::System>& s_, const Mat& Q_, const Mat& psi) : s(s_), PSI(psi), Q(Q_), custom_Q(true) {}
 BatchILQRCP::BatchILQRCP(const std::shared_ptr<sys::System>& s_, const Mat& psi) : s(s_), PSI(psi), custom_Q(false) {}
 
-BatchResult BatchILQRCP::solveBatch(const BatchInputs& in, int nb_iter, bool early_stop) {
-    const int T = s->getHorizon(), nu = s->getNbCtrlVar();
-    if (PSI.rows != (T - 1) * nu) throw std::runtime_error("[BatchILQRCP] psi must have (horizon-1)*nb_ctrl_var rows");
+// psi == nullptr: BatchILQR (identity basis, never materialised)
+static BatchResult batch_gauss_newton(sys::System& s, const Mat* psi, const Mat* Q, const BatchInputs& in, int nb_iter, bool early_stop) {
+    const int T = s.getHorizon(), nu = s.getNbCtrlVar();
+    if (psi && psi->rows != (T - 1) * nu) throw std::runtime_error("[BatchILQRCP] psi must have (horizon-1)*nb_ctrl_var rows");
     ilqr_problem_desc d;
-    s->lower(&d);
-    if (custom_Q) {  // BatchILQRCP.cpp:21-26: a user Q replaces the keypoints' precisions; the device takes its diagonal blocks
-        const int nq = s->getNbQVar(), nkp = d.n_kp;
-        if (Q.rows != nkp * nq || Q.cols != nkp * nq) throw std::runtime_error("[BatchILQRCP] Q must be (n_keypoints*nb_Q_var) square (sparse form)");
-        for (int a = 0; a < Q.rows; a++)
-            for (int b = 0; b < Q.cols; b++) {
-                if (a / nq == b / nq) d.kp_Q[a / nq][(a % nq) * nq + (b % nq)] = Q(a, b);
-                else if (Q(a, b) != 0.0) throw std::runtime_error("[ilqr_hip] a Q coupling different keypoints is not supported on the device");
+    s.lower(&d);
+    if (Q) {  // BatchILQRCP.cpp:21-26 / BatchILQR.cpp:22-26: a user Q replaces the keypoints' precisions; the device takes its diagonal blocks
+        const int nq = s.getNbQVar(), nkp = d.n_kp;
+        if (Q->rows != nkp * nq || Q->cols != nkp * nq) throw std::runtime_error("[BatchILQRCP] Q must be (n_keypoints*nb_Q_var) square (sparse form)");
+        for (int a = 0; a < Q->rows; a++)
+            for (int b = 0; b < Q->cols; b++) {
+                if (a / nq == b / nq) d.kp_Q[a / nq][(a % nq) * nq + (b % nq)] = (*Q)(a, b);
+                else if ((*Q)(a, b) != 0.0) throw std::runtime_error("[ilqr_hip] a Q coupling different keypoints is not supported on the device");
             }
     }
     BatchInputs in2 = in;
     in2.want_gains = false;
-    return run_batch(*s, in2, nb_iter, false, &d, nullptr,
-                     [&](ilqr_problem* p) { check(ilqr_solve_batch_cp(p, PSI.d.data(), PSI.cols, nb_iter, early_stop)); }, nullptr);
+    return run_batch(s, in2, nb_iter, false, &d, nullptr,
+                     [&](ilqr_problem* p) {
+                         if (psi) check(ilqr_solve_batch_cp(p, psi->d.data(), psi->cols, nb_iter, early_stop));
+                         else check(ilqr_solve_batch(p, nb_iter, early_stop));
+                     },
+                     nullptr);
+}
+
+BatchResult BatchILQRCP::solveBatch(const BatchInputs& in, int nb_iter, bool early_stop) {
+    return batch_gauss_newton(*s, &PSI, custom_Q ? &Q : nullptr, in, nb_iter, early_stop);
+}
+
+BatchILQR::BatchILQR(const std::shared_ptr<sys::System>& s_, const Mat& Q_) : s(s_), Q(Q_), custom_Q(true) {}
+BatchILQR::BatchILQR(const std::shared_ptr<sys::System>& s_) : s(s_), custom_Q(false) {}
+BatchResult BatchILQR::solveBatch(const BatchInputs& in, int nb_iter, bool early_stop) {
+    return batch_gauss_newton(*s, nullptr, custom_Q ? &Q : nullptr, in, nb_iter, early_stop);
+}
+Vec BatchILQR::solve(int nb_iter, const Vec& u0, bool early_stop, CallBackMessage* cb) {  // BatchILQR.cpp:110-173
+    BatchInputs in;
+    in.B = 1;
+    in.U0 = u0;
+    in.want_fX = false;
+    const BatchResult r = solveBatch(in, nb_iter, early_stop);
+    emit_trace(r, cb, false);
+    s->reset();
+    return r.U;
 }
 
 Vec BatchILQRCP::solve(int nb_iter, const Vec& u0, bool early_stop, CallBackMessage* cb) {  // BatchILQRCP.cpp:109-175

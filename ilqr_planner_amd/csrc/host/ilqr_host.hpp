@@ -479,6 +479,19 @@ private:
     std::vector<Vec> multipliers;  // persists across solve() calls like the reference's member
 };
 
+class BatchILQR {  // BatchILQR.h:21-53: the batch solver on the full control sequence (= BatchILQRCP with the identity basis)
+public:
+    BatchILQR(const std::shared_ptr<sys::System>& s, const Mat& Q);
+    explicit BatchILQR(const std::shared_ptr<sys::System>& s);
+    Vec solve(int nb_iter, const Vec& u0, bool early_stop = true, CallBackMessage* cb = nullptr);
+    BatchResult solveBatch(const BatchInputs& in, int nb_iter, bool early_stop = true);
+
+private:
+    std::shared_ptr<sys::System> s;
+    Mat Q;  // only the block-diagonal of the keypoints' precisions is supported on the device
+    bool custom_Q = false;
+};
+
 class BatchILQRCP {  // BatchILQRCP.h:21-52
 public:
     BatchILQRCP(const std::shared_ptr<sys::System>& s, const Mat& Q, const Mat& psi);

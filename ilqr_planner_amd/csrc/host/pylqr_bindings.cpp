@@ -291,6 +291,16 @@ PYBIND11_MODULE(PyLQR, m) {
                 const py::object& kp) { return self.solveBatch(batch_inputs(U0, q0, dq0, kp), nb_iter, lag, pen, sc, ls, es); },
              py::arg("U0"), py::arg("nb_iter"), py::arg("lag_update_step"), py::arg("penalty"), py::arg("scaling_factor"), py::arg("line_search"),
              py::arg("early_stop"), py::arg("q0") = py::none(), py::arg("dq0") = py::none(), py::arg("kp_targets") = py::none());
+    // bindings.cpp:778-782
+    py::class_<solver::BatchILQR>(m_sol, "BatchILQR")
+        .def(py::init<const std::shared_ptr<sys::System>&, const Mat&>(), py::arg("s"), py::arg("Q"))
+        .def(py::init<const std::shared_ptr<sys::System>&>(), py::arg("s"))
+        .def("solve", &solver::BatchILQR::solve, py::arg("nb_iter"), py::arg("u0"), py::arg("early_stop"), py::arg("cb"))
+        .def("solve_batch",
+             [](solver::BatchILQR& self, int nb_iter, const py::object& u0, bool es, const py::object& q0, const py::object& dq0, const py::object& kp) {
+                 return self.solveBatch(batch_inputs(u0, q0, dq0, kp, true), nb_iter, es);
+             },
+             py::arg("nb_iter"), py::arg("u0"), py::arg("early_stop"), py::arg("q0") = py::none(), py::arg("dq0") = py::none(), py::arg("kp_targets") = py::none());
     py::class_<solver::BatchILQRCP>(m_sol, "BatchILQRCP")
         .def(py::init<const std::shared_ptr<sys::System>&, const Mat&, const Mat&>(), py::arg("s"), py::arg("Q"), py::arg("psi"))
         .def(py::init<const std::shared_ptr<sys::System>&, const Mat&>(), py::arg("s"), py::arg("psi"))

@@ -41,6 +41,20 @@ struct CPArgs {
     int Kw, it, early_stop, n_alpha;
 };
 
+// Wide bases (Kw > 16) and BatchILQR's identity basis (psi_host == nullptr, Kw = (T-1) n_u): ilqr_batchwide.hip
+struct BatchWideState {
+    std::vector<void*> allocs;
+    long long key = -1;  // (m, N, Bp, kind) the buffers were sized for
+    // LTI systems: shared tables
+    double *G = nullptr, *Et = nullptr, *ZPZ = nullptr, *PZ = nullptr;
+    // per instance
+    double *xbk = nullptr, *av = nullptr, *v0 = nullptr, *p0 = nullptr, *scal = nullptr, *cv = nullptr, *beta = nullptr, *Mx = nullptr, *rhs = nullptr,
+           *Ckp = nullptr, *rkp = nullptr, *u0hat = nullptr, *g0 = nullptr, *y0 = nullptr, *psi = nullptr, *h0inv = nullptr;
+};
+int batchwide_solve(BatchWideState& st, const DevDesc& h, Bufs& bufs, int nx, int nu, const double* psi_host, int Kw, int nb_iter, int early_stop,
+                    hipStream_t stream, std::string& err);
+void batchwide_free(BatchWideState& st);
+
 int batchcp_solve(BatchCPState& st, const DevDesc& h, Bufs& bufs, int nx, int nu, int nf, int nq, const double* psi_host, int Kw,
                   int nb_iter, int early_stop, hipStream_t stream, std::string& err);
 void batchcp_free(BatchCPState& st);

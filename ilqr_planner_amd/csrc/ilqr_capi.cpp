@@ -53,6 +53,7 @@ struct ilqr_problem {
     int last_nb_iter = 0;
     bool has_controls = false, has_state = false;
     BatchCPState cp;
+    BatchWideState cpw;
 };
 
 static int fail(ilqr_ctx* c, const std::string& m) {
@@ -349,6 +350,7 @@ extern "C" void ilqr_problem_destroy(ilqr_problem* p) {
     for (void* q : p->allocs) (void)hipFree(q);
     if (p->staging) (void)hipFree(p->staging);
     batchcp_free(p->cp);
+    batchwide_free(p->cpw);
     delete p;
 }
 
@@ -573,8 +575,23 @@ extern "C" int ilqr_solve_batch_cp(ilqr_problem* p, const double* psi, int Kw, i
     std::string err;
     if (ensure_trace(p, nb_iter)) return 1;
     p->last_nb_iter = nb_iter;
+    if (psi && Kw > 16) {  // wide basis: low-rank form of the normal equations (ilqr_batchwide.hip)
+        if (batchwide_solve(p->cpw, p->hdesc, p->bufs, p->dims.n_x, p->dims.n_u, psi, Kw, nb_iter, early_stop, c->stream, err)) return fail(c, err);
+        return 0;
+    }
     if (batchcp_solve(p->cp, p->hdesc, p->bufs, p->dims.n_x, p->dims.n_u, p->dims.n_f, p->dims.n_Q, psi, Kw, nb_iter, early_stop, c->stream, err))
         return fail(c, err);
+    return 0;
+}
+
+extern "C" int ilqr_solve_batch(ilqr_problem* p, int nb_iter, int early_stop) {
+    if (!p) return 1;
+    ilqr_ctx* c = p->ctx;
+    if (!p->has_state || !p->has_controls) return fail(c, "set_init_state and set_controls must be called before a solve");
+    std::string err;
+    if (ensure_trace(p, nb_iter)) return 1;
+    p->last_nb_iter = nb_iter;
+    if (batchwide_solve(p->cpw, p->hdesc, p->bufs, p->dims.n_x, p->dims.n_u, nullptr, 0, nb_iter, early_stop, c->stream, err)) return fail(c, err);
     return 0;
 }
 

@@ -167,6 +167,9 @@ int ilqr_solve_al(ilqr_problem* p, int nb_iter, int lag_update_step, double pena
 /* BatchILQRCP::solve(nb_iter, u0, early_stop, cb) (src/solver/BatchILQRCP.cpp:109-175) with the shared basis
  * PSI ((T-1) n_u x Kw, row-major); u0 = the controls set with ilqr_problem_set_controls. */
 int ilqr_solve_batch_cp(ilqr_problem* p, const double* psi, int Kw, int nb_iter, int early_stop);
+/* BatchILQR::solve(nb_iter, u0, early_stop, cb) (src/solver/BatchILQR.cpp:110-173): Gauss-Newton on the whole control
+ * sequence, i.e. BatchILQRCP with the identity basis (Kw = (T-1) n_u); the identity is never materialised. */
+int ilqr_solve_batch(ilqr_problem* p, int nb_iter, int early_stop);
 
 /* ---- results (host, natural layout); each synchronises the stream ------------------------------------------ */
 int ilqr_problem_get_X(ilqr_problem* p, double* X);       /* [B][T][n_x]     ILQRRecursive tuple<0> */

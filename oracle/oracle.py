@@ -390,6 +390,12 @@ def solve_batch_cp(s: System, psi, u0, nb_iter, early_stop=True):
     return dict(u=u, iters=n, trace_cost=tc[:n], trace_alpha=ta[:n])
 
 
+def solve_batch(s: System, u0, nb_iter, early_stop=True):
+    """BatchILQR::solve (reference src/solver/BatchILQR.cpp:110-173).  The file differs from BatchILQRCP.cpp only in the absence
+    of PSI (lstq_A = Su'(J'QJ+L)Su + R, du = lstq_A^-1 lstq_B): it is the control-primitive solver with PSI = I, run as such."""
+    return solve_batch_cp(s, np.eye((s.T - 1) * s.n_u), u0, nb_iter, early_stop)
+
+
 def psi(kind: str, dim: int, K: int):
     out = np.zeros((dim, 2 * K if kind == "linear" else K))
     getattr(lib(), "orc_psi_" + kind)(dim, K, _dp(out))

@@ -69,9 +69,9 @@ def test_cp_random_batch_vs_oracle(ctx, cfg_name, B, nb_iter):
 def test_cp_errors(ctx):
     from ilqr_planner_amd import workloads
 
-    cfg = workloads.config("C5")
+    cfg = workloads.config("C4cp")  # wide bases (Kw > 16) exist for the constant-dt systems and, on time systems, for PSI = I only
     desc, inp = workloads.make_batch(ctx, cfg, B=4)
     p = workloads.load_batch(ctx, desc, inp, 4)
-    with pytest.raises(RuntimeError, match="Kw > 16"):
-        p.solve_batch_cp(np.zeros(((cfg["T"] - 1) * 7, 28)), 1, False)
+    with pytest.raises(RuntimeError, match="identity basis"):
+        p.solve_batch_cp(np.zeros(((cfg["T"] - 1) * 8, 24)), 1, False)
     p.close()

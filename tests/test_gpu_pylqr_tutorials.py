@@ -82,6 +82,26 @@ def test_pos_orn_sys_tutorial(capsys):
     np.testing.assert_allclose(F_X2[99, :3], kps[1].get_position(), atol=2e-3)
     np.testing.assert_allclose(rbt.get_q(), q0)  # the solver leaves the simulator at reset() (ILQRRecursive.cpp:179)
 
+    # planner3 = BatchILQR(sys) (cells 12, 16): Gauss-Newton on all 693 controls
+    from PyLQR.solver import BatchILQR
+
+    U3 = BatchILQR(sys_).solve(10, u0, True, cb)
+    _check_stream(capsys.readouterr().out.strip().splitlines(), g["solves"][2]["trace"])
+    U3 = np.asarray(U3).reshape((horizon - 1, nb_ctrl_var))
+    rbt.set_conf(q0, dq0, True)
+    for i in range(horizon - 1):
+        rbt.send_vel(dt, U3[i], True)
+    np.testing.assert_allclose(rbt.get_ee_pos(), kps[1].get_position(), atol=2e-3)
+    # a user Q equal to the system's own gives the same solve (BatchILQR.cpp:22-26); keypoint-coupling Q is refused
+    rbt.set_conf(q0, dq0, True)
+    U3q = BatchILQR(sys_, sys_.get_Q_matrix(True)).solve(10, u0, True, cb)
+    capsys.readouterr()
+    np.testing.assert_array_equal(np.asarray(U3q).reshape(U3.shape), U3)
+    Qc = np.array(sys_.get_Q_matrix(True))
+    Qc[0, 6] = Qc[6, 0] = 0.1
+    with pytest.raises(RuntimeError, match="coupling different keypoints"):
+        BatchILQR(sys_, Qc).solve(1, u0, True, cb)
+
 
 def test_al_ilqr_tutorial(capsys):
     from PyLQR.sim import KDLRobot
@@ -136,6 +156,13 @@ def test_time_sys_tutorial_and_batch(capsys):
     X2, F_X2, U2, K2, k2, cost = planner2.solve(u0.reshape((-1, 8)), 20, True, True, cb)
     _check_stream(capsys.readouterr().out.strip().splitlines(), g["solves"][1]["trace"])
     assert np.asarray(K2).shape == (99, 8, 8) and abs(np.asarray(X2)[-1, -1] - 5.0) < 0.2  # final time near its 5 s target
+
+    # planner3 = BatchILQR(sys).solve(40, u0, True, cb) (cells 8, 12): 792 controls, per-instance sensitivities
+    from PyLQR.solver import BatchILQR
+
+    U3 = BatchILQR(sys_).solve(40, u0, True, cb)
+    _check_stream(capsys.readouterr().out.strip().splitlines(), g["solves"][2]["trace"])
+    assert np.asarray(U3).shape == (99 * 8,)
 
     # new batched entry point: 32 instances with their own start configurations, same System
     rng = np.random.default_rng(0)
