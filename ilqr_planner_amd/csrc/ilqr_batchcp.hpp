@@ -45,10 +45,11 @@ struct CPArgs {
 struct BatchWideState {
     std::vector<void*> allocs;
     long long key = -1;  // (m, N, Bp, kind) the buffers were sized for
+    std::vector<double> tab_sig, tab_psi;  // what the shared tables on the device were built from (rebuilt only when it changes)
     // LTI systems: shared tables
     double *G = nullptr, *Et = nullptr, *ZPZ = nullptr, *PZ = nullptr;
     // per instance
-    double *xbk = nullptr, *av = nullptr, *v0 = nullptr, *p0 = nullptr, *scal = nullptr, *cv = nullptr, *beta = nullptr, *Mx = nullptr, *rhs = nullptr,
+    double *xbk = nullptr, *av = nullptr, *v0 = nullptr, *p0 = nullptr, *scal = nullptr, *cv = nullptr, *beta = nullptr,
            *Ckp = nullptr, *rkp = nullptr, *u0hat = nullptr, *g0 = nullptr, *y0 = nullptr, *psi = nullptr, *h0inv = nullptr;
 };
 int batchwide_solve(BatchWideState& st, const DevDesc& h, Bufs& bufs, int nx, int nu, const double* psi_host, int Kw, int nb_iter, int early_stop,

@@ -36,7 +36,7 @@ namespace ilqr {
 
 struct WArgs {
     const double *G, *Et, *ZPZ, *PZ;  // shared tables (LTI)
-    double *xbk, *av, *v0, *p0, *scal, *cv, *beta, *Mx, *rhs, *Ckp, *rkp;
+    double *xbk, *av, *v0, *p0, *scal, *cv, *beta, *Ckp, *rkp;
     const double* u0hat;
     int m, it, early_stop;
 };
@@ -52,6 +52,25 @@ ILQR_DEV void lin_step(const DevDesc& d, double* s, const double* u) {
             s[i] += dt * s[DOF + i] + hdt2 * u[i];
             s[DOF + i] += dt * u[i];
         }
+    }
+}
+
+// Out-of-line keypoint evaluations (FK, log map, J'QJ): the iteration kernels call them a few times from different places; one
+// copy each keeps their registers and code out of the callers' loops.
+template <class S>
+__device__ __noinline__ double w_kp_cost(const DevDesc* d, const double* kp_tg, int b, int kpi, const double* xt) {
+    const int Bp = d->Bp;
+    double tg[S::NF];
+    UNR for (int i = 0; i < S::NF; i++) tg[i] = AT(kp_tg, kpi * S::NF + i, b);
+    return kp_cost<S>(*d, kpi, tg, xt, nullptr);
+}
+template <class S>
+__device__ __noinline__ void w_kp_derivs(const DevDesc* d, const Bufs* a, int b, int kpi, const double* xt, double* lxx_out, double* lx_out) {
+    double lxx[S::NX][S::NX], lx[S::NX];
+    stage_derivs<S, false>(*d, *a, b, xt, kpi, lxx, lx);  // lxx = J'QJ, lx = -J'Q e
+    UNR for (int i = 0; i < S::NX; i++) {
+        lx_out[i] = lx[i];
+        UNR for (int j = 0; j < S::NX; j++) lxx_out[i * S::NX + j] = lxx[i][j];
     }
 }
 
@@ -148,10 +167,9 @@ ILQR_DEV double wl_task_cost(const DevDesc& d, const Bufs& a, const WArgs& c, in
     const int Bp = d.Bp;
     double cost_e = 0, cost_l = 0;
     for (int kpi = 0; kpi < d.n_kp; kpi++) {
-        double x[NX], xp[NX], tg[S::NF];
+        double x[NX], xp[NX];
         wl_states<S, MC>(d, c, b, kpi, beta, cv, dv, al, x, xp);
-        UNR for (int r = 0; r < S::NF; r++) tg[r] = AT(a.kp_tg, kpi * S::NF + r, b);
-        cost_e += kp_cost<S>(d, kpi, tg, x, nullptr);
+        cost_e += w_kp_cost<S>(&d, a.kp_tg, b, kpi, x);
         if (d.kp_t[kpi] > 0) {
             double Ld[NX], ql[NX];
             limit_terms<S>(d, xp, Ld, ql);
@@ -161,11 +179,13 @@ ILQR_DEV double wl_task_cost(const DevDesc& d, const Bufs& a, const WArgs& c, in
     return cost_e + cost_l;
 }
 
-#define MX(r, q) AT(c.Mx, (size_t)(r) * m + (q), b)
-#define RH(r) AT(c.rhs, r, b)
+// the m x (m+1) system [I + C G | rhs] of one instance lives in LDS, column `lane` of an [m (m+1)][LPB] tile
+#define MX(r, q) lds[((r) * (m + 1) + (q)) * LPB + lane]
+#define RH(r) MX(r, m)
 
-// M x = rhs by LU with partial pivoting, in place in the per-instance scratch (column b of Mx / rhs); x left in rhs
-ILQR_DEV void wide_lu_solve(const WArgs& c, int m, int b, int Bp) {
+// M x = rhs by LU with partial pivoting, in place; x left in the rhs column
+template <int LPB>
+ILQR_DEV void wide_lu_solve(double* lds, int m, int lane) {
     for (int k = 0; k < m; k++) {
         int pr = k;
         double pv = fabs(MX(k, k));
@@ -174,14 +194,12 @@ ILQR_DEV void wide_lu_solve(const WArgs& c, int m, int b, int Bp) {
             if (v > pv) { pv = v; pr = i; }
         }
         if (pr != k) {
-            for (int q = k; q < m; q++) { const double t0 = MX(k, q); MX(k, q) = MX(pr, q); MX(pr, q) = t0; }
-            const double t1 = RH(k); RH(k) = RH(pr); RH(pr) = t1;
+            for (int q = k; q <= m; q++) { const double t0 = MX(k, q); MX(k, q) = MX(pr, q); MX(pr, q) = t0; }
         }
-        const double piv = MX(k, k), rk = RH(k);
+        const double piv = MX(k, k);
         for (int i = k + 1; i < m; i++) {
             const double f = MX(i, k) / piv;
-            for (int q = k + 1; q < m; q++) MX(i, q) -= f * MX(k, q);
-            RH(i) -= f * rk;
+            for (int q = k + 1; q <= m; q++) MX(i, q) -= f * MX(k, q);
         }
     }
     for (int i = m - 1; i >= 0; i--) {
@@ -191,11 +209,14 @@ ILQR_DEV void wide_lu_solve(const WArgs& c, int m, int b, int Bp) {
     }
 }
 
-template <class S, int MC>
-__global__ __launch_bounds__(64) void k_wl_iter(Bufs a, WArgs c) {
+// LPB lanes (instances) per block: the LDS tile of the linear system bounds it (m = 14: 32 lanes x 1.7 KB; m = 28: 16 lanes x 6.5 KB),
+// and smaller blocks mean more of them: the kernel is latency-bound, not throughput-bound (B / LPB waves for 256 CUs)
+template <class S, int MC, int LPB>
+__global__ __launch_bounds__(LPB) void k_wl_iter(Bufs a, WArgs c) {
     constexpr int NX = S::NX;
+    extern __shared__ double lds[];
     const DevDesc& d = *a.desc;
-    const int b = blockIdx.x * 64 + threadIdx.x;
+    const int lane = threadIdx.x, b = blockIdx.x * LPB + lane;
     if (b >= d.B || !a.active[b]) return;
     const int Bp = d.Bp, m = c.m;
     double cv[MC], dv[MC];
@@ -205,17 +226,16 @@ __global__ __launch_bounds__(64) void k_wl_iter(Bufs a, WArgs c) {
     // linearisation at the current iterate: C_k = J'QJ + L, r_k = J'Q e + L ql (System::fpBatch + BatchILQRCP.cpp:129-133)
     double cost_e = 0, cost_l = 0;
     for (int kpi = 0; kpi < d.n_kp; kpi++) {
-        double x[NX], xp[NX], lxx[NX][NX], lx[NX], Ld[NX], ql[NX], tg[S::NF];
+        double x[NX], xp[NX], lxx[NX * NX], lx[NX], Ld[NX], ql[NX];
         wl_states<S, MC>(d, c, b, kpi, beta, cv, dv, 0.0, x, xp);
-        stage_derivs<S, false>(d, a, b, x, kpi, lxx, lx);  // lxx = J'QJ, lx = -J'Q e
+        w_kp_derivs<S>(&d, &a, b, kpi, x, lxx, lx);
         if (d.kp_t[kpi] > 0) limit_terms<S>(d, xp, Ld, ql);
         else { UNR for (int r = 0; r < NX; r++) { Ld[r] = 0; ql[r] = 0; } }
-        UNR for (int r = 0; r < S::NF; r++) tg[r] = AT(a.kp_tg, kpi * S::NF + r, b);
-        cost_e += kp_cost<S>(d, kpi, tg, x, nullptr);
+        cost_e += w_kp_cost<S>(&d, a.kp_tg, b, kpi, x);
         UNR for (int r = 0; r < NX; r++) cost_l += ql[r] * Ld[r] * ql[r];
         double* Ck = c.Ckp + (size_t)kpi * NX * NX * Bp;
         UNR for (int r = 0; r < NX; r++) {
-            UNR for (int s = 0; s < NX; s++) AT(Ck, r * NX + s, b) = lxx[r][s] + ((r == s) ? Ld[r] : 0.0);
+            UNR for (int s = 0; s < NX; s++) AT(Ck, r * NX + s, b) = lxx[r * NX + s] + ((r == s) ? Ld[r] : 0.0);
             AT(c.rkp, kpi * NX + r, b) = -lx[r] + Ld[r] * ql[r];
         }
     }
@@ -248,7 +268,7 @@ __global__ __launch_bounds__(64) void k_wl_iter(Bufs a, WArgs c) {
             }
         }
     }
-    wide_lu_solve(c, m, b, Bp);
+    wide_lu_solve<LPB>(lds, m, lane);
     UNR for (int j = 0; j < MC; j++) dv[j] = (j < m) ? RH(j) : 0.0;
 
     // ||PSI dw||^2, dw = Z d - beta y0;  pieces of the control cost along the step
@@ -372,16 +392,16 @@ __global__ __launch_bounds__(64) void k_wt_roll(Bufs a, WTArgs c) {
     double cost_e = 0, cost_u = 0, cost_l = 0;
     int kpi = 0;
     auto record = [&](int i) {
-        double lxx[NX][NX], lx[NX], Ld[NX], ql[NX], tg[S::NF];
-        stage_derivs<S, false>(d, a, b, x, kpi, lxx, lx);
+        double lxx[NX * NX], lx[NX], Ld[NX], ql[NX], xt[NX];
+        UNR for (int r = 0; r < NX; r++) xt[r] = x[r];
+        w_kp_derivs<S>(&d, &a, b, kpi, xt, lxx, lx);
         if (i > 0) limit_terms<S>(d, xp, Ld, ql);
         else { UNR for (int r = 0; r < NX; r++) { Ld[r] = 0; ql[r] = 0; } }
-        UNR for (int r = 0; r < S::NF; r++) tg[r] = AT(a.kp_tg, kpi * S::NF + r, b);
-        cost_e += kp_cost<S>(d, kpi, tg, x, nullptr);
+        cost_e += w_kp_cost<S>(&d, a.kp_tg, b, kpi, xt);
         UNR for (int r = 0; r < NX; r++) cost_l += ql[r] * Ld[r] * ql[r];
         double* Ck = c.Ckp + (size_t)kpi * NX * NX * Bp;
         UNR for (int r = 0; r < NX; r++) {
-            UNR for (int s = 0; s < NX; s++) AT(Ck, r * NX + s, b) = lxx[r][s] + ((r == s) ? Ld[r] : 0.0);
+            UNR for (int s = 0; s < NX; s++) AT(Ck, r * NX + s, b) = lxx[r * NX + s] + ((r == s) ? Ld[r] : 0.0);
             AT(c.rkp, kpi * NX + r, b) = -lx[r] + Ld[r] * ql[r];
         }
         kpi++;
@@ -556,9 +576,9 @@ __global__ __launch_bounds__(64) void k_wt_linesearch(Bufs a, WTArgs c) {
         double cost_e = 0, cost_u = 0, cost_l = 0;
         int kpi = 0;
         auto kp_here = [&](int i) {
-            double tg[S::NF];
-            UNR for (int r = 0; r < S::NF; r++) tg[r] = AT(a.kp_tg, kpi * S::NF + r, b);
-            cost_e += kp_cost<S>(d, kpi, tg, x, nullptr);
+            double xt[NX];
+            UNR for (int r = 0; r < NX; r++) xt[r] = x[r];
+            cost_e += w_kp_cost<S>(&d, a.kp_tg, b, kpi, xt);
             if (i > 0) {
                 double Ld[NX], ql[NX];
                 limit_terms<S>(d, xp, Ld, ql);
@@ -674,108 +694,18 @@ static int run_wl(BatchWideState& st, const DevDesc& h, Bufs& bufs, const double
     for (int i = 0; i < NU; i++)
         if (!(h.R_diag[i] > 0)) { err = "wide-basis batch solve: the control penalty RtDiag must be positive"; return 1; }
 
-    // sensitivities at the keypoint steps by their recurrences: Wt_{i+1} = A Wt_i + B PSI_i from Wt_0 = 0 (true), and the
-    // reference's shifted Wr_{i+1} = A Wr_i + B PSI_i from Wr_1 = 0, i >= 1 (BatchILQRCP.cpp:61-97, quirk D-1).  NX x Kw, row-major.
-    auto advance = [&](std::vector<double>& W, int i) {
-        if (ND == 2)
-            for (int r = 0; r < DOF; r++)
-                for (int q = 0; q < Kw; q++) W[(size_t)r * Kw + q] += dt * W[(size_t)(DOF + r) * Kw + q];
-        for (int r = 0; r < DOF; r++) {
-            if (ident) {
-                const int q = i * NU + r;
-                if (ND == 1) W[(size_t)r * Kw + q] += dt;
-                else { W[(size_t)r * Kw + q] += hdt2; W[(size_t)(DOF + r) * Kw + q] += dt; }
-            } else {
-                const double* pr = psi + (size_t)(i * NU + r) * Kw;
-                for (int q = 0; q < Kw; q++) {
-                    if (ND == 1) W[(size_t)r * Kw + q] += dt * pr[q];
-                    else { W[(size_t)r * Kw + q] += hdt2 * pr[q]; W[(size_t)(DOF + r) * Kw + q] += dt * pr[q]; }
-                }
-            }
-        }
-    };
-    std::vector<std::vector<double>> wt(2 * nkp, std::vector<double>((size_t)NX * Kw, 0.0));  // [kp][which]
-    std::vector<double> V((size_t)m * Kw, 0.0);
-    {
-        std::vector<double> Wt((size_t)NX * Kw, 0.0), Wr((size_t)NX * Kw, 0.0);
-        auto sample = [&](int i) {  // Wt = Wt_i, Wr = Wr_i
-            for (int t = 0; t < nkp; t++) {
-                if (h.kp_t[t] == i) { wt[2 * t + 0] = Wt; std::copy(Wr.begin(), Wr.end(), V.begin() + (size_t)t * NX * Kw); }
-                if (h.kp_t[t] - 1 == i) wt[2 * t + 1] = Wt;
-            }
-        };
-        sample(0);
-        for (int i = 0; i + 1 < T; i++) {
-            advance(Wt, i);
-            if (i >= 1) advance(Wr, i);
-            sample(i + 1);
-        }
-    }
-    // Z = H0^-1 V' (Kw x m)
-    std::vector<double> Z((size_t)Kw * m, 0.0), h0inv;
-    bool diag = ident;
-    if (ident) {
-        for (int q = 0; q < Kw; q++)
-            for (int j = 0; j < m; j++) Z[(size_t)q * m + j] = V[(size_t)j * Kw + q] / h.R_diag[q % NU];
-    } else {
-        h0inv.assign((size_t)Kw * Kw, 0.0);
-        for (int k = 0; k < N; k++) {
-            const double* pr = psi + (size_t)k * Kw;
-            const double rk = h.R_diag[k % NU];
-            for (int a_ = 0; a_ < Kw; a_++) {
-                if (pr[a_] == 0.0) continue;
-                const double pa = pr[a_] * rk;
-                for (int b_ = 0; b_ < Kw; b_++) h0inv[(size_t)a_ * Kw + b_] += pa * pr[b_];
-            }
-        }
-        if (!spd_inverse(h0inv, Kw)) { err = "wide-basis batch solve: PSI'R PSI is not positive definite (PSI must have full column rank)"; return 1; }
-        for (int q = 0; q < Kw; q++)
-            for (int j = 0; j < m; j++) {
-                double s = 0;
-                for (int r = 0; r < Kw; r++) s += h0inv[(size_t)q * Kw + r] * V[(size_t)j * Kw + r];
-                Z[(size_t)q * m + j] = s;
-            }
-    }
-    (void)diag;
-    std::vector<double> G((size_t)m * m, 0.0), Et((size_t)nkp * 2 * NX * m, 0.0), PZ((size_t)N * m, 0.0), ZPZ((size_t)m * m, 0.0);
-    for (int i = 0; i < m; i++)
-        for (int q = 0; q < Kw; q++) {
-            const double v = V[(size_t)i * Kw + q];
-            if (v == 0.0) continue;
-            for (int j = 0; j < m; j++) G[(size_t)i * m + j] += v * Z[(size_t)q * m + j];
-        }
-    for (int i = 0; i < m; i++)  // symmetric in exact arithmetic; the kernel relies on it
-        for (int j = 0; j < i; j++) G[(size_t)i * m + j] = G[(size_t)j * m + i] = 0.5 * (G[(size_t)i * m + j] + G[(size_t)j * m + i]);
-    for (int t = 0; t < 2 * nkp; t++)
-        for (int r = 0; r < NX; r++)
-            for (int q = 0; q < Kw; q++) {
-                const double v = wt[t][(size_t)r * Kw + q];
-                if (v == 0.0) continue;
-                for (int j = 0; j < m; j++) Et[((size_t)t * NX + r) * m + j] += v * Z[(size_t)q * m + j];
-            }
-    if (ident) PZ = Z;
-    else
-        for (int k = 0; k < N; k++)
-            for (int q = 0; q < Kw; q++) {
-                const double v = psi[(size_t)k * Kw + q];
-                if (v == 0.0) continue;
-                for (int j = 0; j < m; j++) PZ[(size_t)k * m + j] += v * Z[(size_t)q * m + j];
-            }
-    for (int k = 0; k < N; k++)
-        for (int i = 0; i < m; i++) {
-            const double v = PZ[(size_t)k * m + i];
-            if (v == 0.0) continue;
-            for (int j = 0; j < m; j++) ZPZ[(size_t)i * m + j] += v * PZ[(size_t)k * m + j];
-        }
-
+    // the shared tables depend on (system shape, dt, keypoint steps, R, PSI) only: keep them on the device across solves
+    std::vector<double> sig = {(double)h.kind, (double)ND, (double)T, dt, (double)nkp, (double)Kw, ident ? 1.0 : 0.0};
+    for (int t = 0; t < nkp; t++) sig.push_back(h.kp_t[t]);
+    for (int i = 0; i < NU; i++) sig.push_back(h.R_diag[i]);
     const long long key = (((long long)m * 100003 + N) * 100003 + Bp) * 8 + h.kind * 2 + (ident ? 1 : 0) + (long long)Kw * 1000000007LL;
-    if (st.key != key) {
+    const bool fresh = st.key != key;
+    if (fresh) {
         batchwide_free(st);
         bool ok = w_alloc(st, &st.G, (size_t)m * m, stream) && w_alloc(st, &st.ZPZ, (size_t)m * m, stream) && w_alloc(st, &st.Et, (size_t)nkp * 2 * NX * m, stream) &&
                   w_alloc(st, &st.PZ, (size_t)N * m, stream) && w_alloc(st, &st.xbk, (size_t)nkp * 2 * NX * Bp, stream) &&
                   w_alloc(st, &st.av, (size_t)nkp * 2 * NX * Bp, stream) && w_alloc(st, &st.v0, (size_t)m * Bp, stream) && w_alloc(st, &st.p0, (size_t)m * Bp, stream) &&
                   w_alloc(st, &st.scal, (size_t)3 * Bp, stream) && w_alloc(st, &st.cv, (size_t)m * Bp, stream) && w_alloc(st, &st.beta, (size_t)Bp, stream) &&
-                  w_alloc(st, &st.Mx, (size_t)m * m * Bp, stream) && w_alloc(st, &st.rhs, (size_t)m * Bp, stream) &&
                   w_alloc(st, &st.Ckp, (size_t)nkp * NX * NX * Bp, stream) && w_alloc(st, &st.rkp, (size_t)m * Bp, stream);
         if (ok && !ident)
             ok = w_alloc(st, &st.u0hat, (size_t)N * Bp, stream) && w_alloc(st, &st.g0, (size_t)Kw * Bp, stream) && w_alloc(st, &st.y0, (size_t)Kw * Bp, stream) &&
@@ -783,14 +713,112 @@ static int run_wl(BatchWideState& st, const DevDesc& h, Bufs& bufs, const double
         if (!ok) { batchwide_free(st); err = "wide-basis batch solve: hipMalloc failed"; return 1; }
         st.key = key;
     }
-    bool up = upload(st.G, G, stream) && upload(st.ZPZ, ZPZ, stream) && upload(st.Et, Et, stream) && upload(st.PZ, PZ, stream);
-    if (up && !ident)
-        up = hipMemcpyAsync(st.psi, psi, (size_t)N * Kw * sizeof(double), hipMemcpyHostToDevice, stream) == hipSuccess && upload(st.h0inv, h0inv, stream);
-    if (!up || hipStreamSynchronize(stream) != hipSuccess) { err = "wide-basis batch solve: table upload failed"; return 1; }
+    const bool same_tables = !fresh && st.tab_sig == sig && (ident || (st.tab_psi.size() == (size_t)N * Kw && !std::memcmp(st.tab_psi.data(), psi, sizeof(double) * N * Kw)));
+    if (!same_tables) {
+        // sensitivities at the keypoint steps by their recurrences: Wt_{i+1} = A Wt_i + B PSI_i from Wt_0 = 0 (true), and the
+        // reference's shifted Wr_{i+1} = A Wr_i + B PSI_i from Wr_1 = 0, i >= 1 (BatchILQRCP.cpp:61-97, quirk D-1).  NX x Kw, row-major.
+        auto advance = [&](std::vector<double>& W, int i) {
+            if (ND == 2)
+                for (int r = 0; r < DOF; r++)
+                    for (int q = 0; q < Kw; q++) W[(size_t)r * Kw + q] += dt * W[(size_t)(DOF + r) * Kw + q];
+            for (int r = 0; r < DOF; r++) {
+                if (ident) {
+                    const int q = i * NU + r;
+                    if (ND == 1) W[(size_t)r * Kw + q] += dt;
+                    else { W[(size_t)r * Kw + q] += hdt2; W[(size_t)(DOF + r) * Kw + q] += dt; }
+                } else {
+                    const double* pr = psi + (size_t)(i * NU + r) * Kw;
+                    for (int q = 0; q < Kw; q++) {
+                        if (ND == 1) W[(size_t)r * Kw + q] += dt * pr[q];
+                        else { W[(size_t)r * Kw + q] += hdt2 * pr[q]; W[(size_t)(DOF + r) * Kw + q] += dt * pr[q]; }
+                    }
+                }
+            }
+        };
+        std::vector<std::vector<double>> wt(2 * nkp, std::vector<double>((size_t)NX * Kw, 0.0));  // [kp][which]
+        std::vector<double> V((size_t)m * Kw, 0.0);
+        {
+            std::vector<double> Wt((size_t)NX * Kw, 0.0), Wr((size_t)NX * Kw, 0.0);
+            auto sample = [&](int i) {  // Wt = Wt_i, Wr = Wr_i
+                for (int t = 0; t < nkp; t++) {
+                    if (h.kp_t[t] == i) { wt[2 * t + 0] = Wt; std::copy(Wr.begin(), Wr.end(), V.begin() + (size_t)t * NX * Kw); }
+                    if (h.kp_t[t] - 1 == i) wt[2 * t + 1] = Wt;
+                }
+            };
+            sample(0);
+            for (int i = 0; i + 1 < T; i++) {
+                advance(Wt, i);
+                if (i >= 1) advance(Wr, i);
+                sample(i + 1);
+            }
+        }
+        // Z = H0^-1 V' (Kw x m)
+        std::vector<double> Z((size_t)Kw * m, 0.0), h0inv;
+        bool diag = ident;
+        if (ident) {
+            for (int q = 0; q < Kw; q++)
+                for (int j = 0; j < m; j++) Z[(size_t)q * m + j] = V[(size_t)j * Kw + q] / h.R_diag[q % NU];
+        } else {
+            h0inv.assign((size_t)Kw * Kw, 0.0);
+            for (int k = 0; k < N; k++) {
+                const double* pr = psi + (size_t)k * Kw;
+                const double rk = h.R_diag[k % NU];
+                for (int a_ = 0; a_ < Kw; a_++) {
+                    if (pr[a_] == 0.0) continue;
+                    const double pa = pr[a_] * rk;
+                    for (int b_ = 0; b_ < Kw; b_++) h0inv[(size_t)a_ * Kw + b_] += pa * pr[b_];
+                }
+            }
+            if (!spd_inverse(h0inv, Kw)) { err = "wide-basis batch solve: PSI'R PSI is not positive definite (PSI must have full column rank)"; return 1; }
+            for (int q = 0; q < Kw; q++)
+                for (int j = 0; j < m; j++) {
+                    double s = 0;
+                    for (int r = 0; r < Kw; r++) s += h0inv[(size_t)q * Kw + r] * V[(size_t)j * Kw + r];
+                    Z[(size_t)q * m + j] = s;
+                }
+        }
+        (void)diag;
+        std::vector<double> G((size_t)m * m, 0.0), Et((size_t)nkp * 2 * NX * m, 0.0), PZ((size_t)N * m, 0.0), ZPZ((size_t)m * m, 0.0);
+        for (int i = 0; i < m; i++)
+            for (int q = 0; q < Kw; q++) {
+                const double v = V[(size_t)i * Kw + q];
+                if (v == 0.0) continue;
+                for (int j = 0; j < m; j++) G[(size_t)i * m + j] += v * Z[(size_t)q * m + j];
+            }
+        for (int i = 0; i < m; i++)  // symmetric in exact arithmetic; the kernel relies on it
+            for (int j = 0; j < i; j++) G[(size_t)i * m + j] = G[(size_t)j * m + i] = 0.5 * (G[(size_t)i * m + j] + G[(size_t)j * m + i]);
+        for (int t = 0; t < 2 * nkp; t++)
+            for (int r = 0; r < NX; r++)
+                for (int q = 0; q < Kw; q++) {
+                    const double v = wt[t][(size_t)r * Kw + q];
+                    if (v == 0.0) continue;
+                    for (int j = 0; j < m; j++) Et[((size_t)t * NX + r) * m + j] += v * Z[(size_t)q * m + j];
+                }
+        if (ident) PZ = Z;
+        else
+            for (int k = 0; k < N; k++)
+                for (int q = 0; q < Kw; q++) {
+                    const double v = psi[(size_t)k * Kw + q];
+                    if (v == 0.0) continue;
+                    for (int j = 0; j < m; j++) PZ[(size_t)k * m + j] += v * Z[(size_t)q * m + j];
+                }
+        for (int k = 0; k < N; k++)
+            for (int i = 0; i < m; i++) {
+                const double v = PZ[(size_t)k * m + i];
+                if (v == 0.0) continue;
+                for (int j = 0; j < m; j++) ZPZ[(size_t)i * m + j] += v * PZ[(size_t)k * m + j];
+            }
+        bool up = upload(st.G, G, stream) && upload(st.ZPZ, ZPZ, stream) && upload(st.Et, Et, stream) && upload(st.PZ, PZ, stream);
+        if (up && !ident)
+            up = hipMemcpyAsync(st.psi, psi, (size_t)N * Kw * sizeof(double), hipMemcpyHostToDevice, stream) == hipSuccess && upload(st.h0inv, h0inv, stream);
+        if (!up || hipStreamSynchronize(stream) != hipSuccess) { err = "wide-basis batch solve: table upload failed"; return 1; }
+        st.tab_sig = sig;
+        if (!ident) st.tab_psi.assign(psi, psi + (size_t)N * Kw);
+    }
 
     WArgs c;
     c.G = st.G; c.Et = st.Et; c.ZPZ = st.ZPZ; c.PZ = st.PZ;
-    c.xbk = st.xbk; c.av = st.av; c.v0 = st.v0; c.p0 = st.p0; c.scal = st.scal; c.cv = st.cv; c.beta = st.beta; c.Mx = st.Mx; c.rhs = st.rhs;
+    c.xbk = st.xbk; c.av = st.av; c.v0 = st.v0; c.p0 = st.p0; c.scal = st.scal; c.cv = st.cv; c.beta = st.beta;
     c.Ckp = st.Ckp; c.rkp = st.rkp;
     c.u0hat = ident ? bufs.U0 : st.u0hat;
     c.m = m; c.it = 0; c.early_stop = early_stop;
@@ -801,9 +829,15 @@ static int run_wl(BatchWideState& st, const DevDesc& h, Bufs& bufs, const double
         hipLaunchKernelGGL(k_w_matvec, dim3((B + 63) / 64, N), block, 0, stream, st.psi, st.y0, bufs.desc, st.u0hat, N, Kw);
     }
     hipLaunchKernelGGL((k_wl_init<S, MC>), grid, block, 0, stream, bufs, c);
+    constexpr int LPB = MC <= 16 ? 32 : 16;
+    const size_t lds_it = sizeof(double) * m * (m + 1) * LPB;
+    if (hipFuncSetAttribute((const void*)k_wl_iter<S, MC, LPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_it) != hipSuccess) {
+        err = "wide-basis batch solve: cannot reserve LDS";
+        return 1;
+    }
     for (int it = 0; it < nb_iter; it++) {
         c.it = it;
-        hipLaunchKernelGGL((k_wl_iter<S, MC>), grid, block, 0, stream, bufs, c);
+        hipLaunchKernelGGL((k_wl_iter<S, MC, LPB>), dim3((B + LPB - 1) / LPB), dim3(LPB), lds_it, stream, bufs, c);
     }
     hipLaunchKernelGGL((k_wl_controls<S, MC>), dim3((B + 63) / 64, T - 1), block, 0, stream, bufs, c);
     hipLaunchKernelGGL((k_wide_final<S>), grid, block, 0, stream, bufs);
