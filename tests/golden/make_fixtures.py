@@ -119,11 +119,12 @@ OBJ1 = frame_of([0.63758403393523, 0.2994657314658187, 0.6042309402208079, -0.37
 OBJ2 = frame_of([-0.03647984, 0.94060485, 0.33742794, 0.00860923], [0.32, 0.05, 0.54])
 
 
-def frame_problem(T, dt, kps, n_sub):
+def frame_problem(T, dt, kps, n_sub, kind="POS_ORN", nb_deriv=1, u0_step=None):
     dof = 7
-    return dict(kind="POS_ORN", nb_deriv=1, T=T, dt=dt, q0=Q0_TUT, dq0=[0] * dof, R_diag=[1e-5] * dof,
+    nu = dof + (1 if kind == "POS_ORN_TIME" else 0)
+    return dict(kind=kind, nb_deriv=nb_deriv, T=T, dt=dt, q0=Q0_TUT, dq0=[0] * dof, R_diag=[1e-5] * nu,
                 qMax=[PI10] * dof, qMin=[-PI10] * dof, dqMax=[10.0] * dof, dqMin=[-10.0] * dof,
-                keypoints=kps, u0_step=[0.0] * dof, base="panda_link0", tip="panda_tip", lim_mult=n_sub)
+                keypoints=kps, u0_step=u0_step if u0_step is not None else [0.0] * nu, base="panda_link0", tip="panda_tip", lim_mult=n_sub)
 
 
 t = traces_of("POS_ORN_SYS_OBJ_FRAME.ipynb")
@@ -139,6 +140,25 @@ cases["POS_ORN_MULTI_SYS"] = dict(  # SequentialSystem(rbt, [sys1 in obj1_frame 
     problem=frame_problem(600, 0.01, [
         dict(timestep=300, pos=[0, 0, -0.15], orn=[1, 0, 0, 0], Qdiag=[1, 1, 1, 0, 0, 0], frame=OBJ1, Ru=[1e-5] * 7),
         dict(timestep=599, pos=[0.1, 0.1, -0.1], orn=[1, 0, 0, 0], Qdiag=[1, 1, 1, 0, 0, 0], frame=OBJ2, Ru=[1e-5] * 7)], 2),
+    solves=[dict(solver="BatchILQRCP", psi=dict(kind="unitstep", K=2), nb_iter=25, early_stop=True, **t[0]),
+            dict(solver="ILQRRecursive", nb_iter=10, line_search=True, early_stop=True, **t[1])])
+
+PV0 = [1, 1, 1, 0, 0, 0]
+t = traces_of("POS_ORN_MULTI_SYS_2ND.ipynb")
+cases["POS_ORN_MULTI_SYS_2ND"] = dict(  # the same two object-frame sub-systems, 2nd order (velocities in the object frames too; cells 12-18)
+    problem=frame_problem(600, 0.01, [
+        dict(timestep=300, pos=[0, 0, -0.15], orn=[1, 0, 0, 0], dpos=[0, 0, 0], dorn=[0, 0, 0, 0], Qdiag=PV0 + PV0, frame=OBJ1, Ru=[1e-5] * 7),
+        dict(timestep=599, pos=[0.1, 0.1, -0.1], orn=[1, 0, 0, 0], dpos=[0, 0, 0], dorn=[0, 0, 0, 0], Qdiag=PV0 + PV0, frame=OBJ2, Ru=[1e-5] * 7)],
+        2, nb_deriv=2),
+    solves=[dict(solver="BatchILQRCP", psi=dict(kind="sawtooth", K=2), nb_iter=25, early_stop=True, **t[0]),
+            dict(solver="ILQRRecursive", nb_iter=10, line_search=True, early_stop=True, **t[1])])
+
+t = traces_of("POS_ORN_MULTI_SYS_TIME.ipynb")
+cases["POS_ORN_MULTI_SYS_TIME"] = dict(  # two PosOrnTimePlannerSys in object frames, SpacetimeKeypoints at 2.5 s / 5 s, u0 = 0.1 everywhere (cell 18)
+    problem=frame_problem(600, None, [
+        dict(timestep=300, pos=[0, 0, -0.15], orn=[1, 0, 0, 0], Qdiag=PV0 + [.1], ctime=2.5, frame=OBJ1, Ru=[1e-5] * 8),
+        dict(timestep=599, pos=[0.1, 0.1, -0.1], orn=[1, 0, 0, 0], Qdiag=PV0 + [.1], ctime=5, frame=OBJ2, Ru=[1e-5] * 8)],
+        2, kind="POS_ORN_TIME", u0_step=[0.1] * 8),
     solves=[dict(solver="BatchILQRCP", psi=dict(kind="unitstep", K=2), nb_iter=25, early_stop=True, **t[0]),
             dict(solver="ILQRRecursive", nb_iter=10, line_search=True, early_stop=True, **t[1])])
 

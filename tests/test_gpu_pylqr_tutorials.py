@@ -277,6 +277,82 @@ def test_multi_sys_tutorial(capsys):
         SequentialSystem(rbt, [sys1, PosOrnPlannerSys(tr2, [], cmd_penalties, qMax, -qMax, dqMax, -dqMax, horizon + 1, 1, dt)], cmd_penalties, horizon, 1)
 
 
+def test_multi_sys_2nd_tutorial(capsys):
+    """POS_ORN_MULTI_SYS_2ND.ipynb: SequentialSystem of two 2nd-order PosOrnPlannerSys in object frames (cells 10-23)."""
+    from PyLQR.sim import KDLRobot, TransformedSimulationInterface
+    from PyLQR.solver import BatchILQRCP, ILQRRecursive
+    from PyLQR.system import PosOrnKeypoint, PosOrnPlannerSys, SequentialSystem
+    from PyLQR.utils import PythonCallbackMessage, primitives
+
+    g = golden()["cases"]["POS_ORN_MULTI_SYS_2ND"]
+    dof, nb_ctrl_var, horizon, dt = 7, 7, 600, 0.01
+    q0, dq0 = g["problem"]["q0"], [0] * dof
+    qMax, dqMax = np.array([np.pi] * dof) * 10, np.array([10] * dof)
+    obj1_frame, obj2_frame = _frame_objs()
+    rbt = KDLRobot(URDF, "panda_link0", "panda_tip", q0, dq0)
+    tr1, tr2 = TransformedSimulationInterface(rbt, obj1_frame), TransformedSimulationInterface(rbt, obj2_frame)
+    cmd_penalties = (np.ones(nb_ctrl_var) * 1e-5).tolist()
+    k1, k2_ = g["problem"]["keypoints"]
+    mk = lambda k: PosOrnKeypoint(np.array(k["pos"]), np.array(k["dpos"]), np.array(k["orn"]), np.array(k["dorn"]), np.diag(k["Qdiag"]), k["timestep"])
+    sys1 = PosOrnPlannerSys(tr1, [mk(k1)], cmd_penalties, qMax, -qMax, dqMax, -dqMax, horizon, 2, dt)
+    sys2 = PosOrnPlannerSys(tr2, [mk(k2_)], cmd_penalties, qMax, -qMax, dqMax, -dqMax, horizon, 2, dt)
+    sys_ = SequentialSystem(rbt, [sys1, sys2], cmd_penalties, horizon, 2)
+    assert (sys_.get_nb_state_var(), sys_.get_nb_ctrl_var(), sys_.get_nb_target_var(), sys_.get_horizon()) == (14, 7, 28, 600)
+    u0 = np.tile(np.array([0] * nb_ctrl_var), horizon - 1)
+    PSI = np.kron(primitives.build_psi_sawtooth(horizon - 1, 2), np.identity(nb_ctrl_var))
+    cb = PythonCallbackMessage()
+    capsys.readouterr()
+    BatchILQRCP(sys_, PSI).solve(25, u0, True, cb)
+    _check_stream(capsys.readouterr().out.strip().splitlines(), g["solves"][0]["trace"])
+    X2, F_X2, U2, K2, k2, cost = ILQRRecursive(sys_).solve(u0.reshape((-1, nb_ctrl_var)), 10, True, True, cb)
+    _check_stream(capsys.readouterr().out.strip().splitlines(), g["solves"][1]["trace"])
+    assert np.asarray(K2).shape == (599, 7, 14)
+    # replay with send_acc: at T/2 the tool is at target 1 of object frame 1 and at rest there, at the end at target 2 of object frame 2
+    rbt.set_conf(q0, dq0, True)
+    U2 = np.asarray(U2)
+    for i in range(horizon - 1):
+        if i == k1["timestep"]:
+            tr1.update_kinematics()
+            np.testing.assert_allclose(tr1.get_ee_pos(), k1["pos"], atol=5e-3)
+            np.testing.assert_allclose(tr1.get_ee_vel(), [0, 0, 0], atol=2e-2)
+        rbt.send_acc(dt, U2[i], True)
+    tr2.update_kinematics()
+    np.testing.assert_allclose(tr2.get_ee_pos(), k2_["pos"], atol=5e-3)
+
+
+def test_multi_sys_time_tutorial(capsys):
+    """POS_ORN_MULTI_SYS_TIME.ipynb: SequentialSystem of two PosOrnTimePlannerSys in object frames, SpacetimeKeypoints (cells 10-23)."""
+    from PyLQR.sim import KDLRobot, TransformedSimulationInterface
+    from PyLQR.solver import BatchILQRCP, ILQRRecursive
+    from PyLQR.system import PosOrnTimePlannerSys, SequentialSystem, SpacetimeKeypoint
+    from PyLQR.utils import PythonCallbackMessage, primitives
+
+    g = golden()["cases"]["POS_ORN_MULTI_SYS_TIME"]
+    dof, nb_ctrl_var, horizon = 7, 8, 600
+    q0, dq0 = g["problem"]["q0"], [0] * dof
+    qMax, dqMax = np.array([np.pi] * dof) * 10, np.array([10] * dof)
+    obj1_frame, obj2_frame = _frame_objs()
+    rbt = KDLRobot(URDF, "panda_link0", "panda_tip", q0, dq0)
+    tr1, tr2 = TransformedSimulationInterface(rbt, obj1_frame), TransformedSimulationInterface(rbt, obj2_frame)
+    cmd_penalties = (np.ones(nb_ctrl_var) * 1e-5).tolist()
+    k1, k2_ = g["problem"]["keypoints"]
+    mk = lambda k: SpacetimeKeypoint(np.array(k["pos"]), np.array(k["orn"]), np.diag(k["Qdiag"]), k["ctime"], k["timestep"])
+    sys1 = PosOrnTimePlannerSys(tr1, [mk(k1)], cmd_penalties, qMax, -qMax, dqMax, -dqMax, horizon, 1)
+    sys2 = PosOrnTimePlannerSys(tr2, [mk(k2_)], cmd_penalties, qMax, -qMax, dqMax, -dqMax, horizon, 1)
+    sys_ = SequentialSystem(rbt, [sys1, sys2], cmd_penalties, horizon, 1)
+    assert (sys_.get_nb_state_var(), sys_.get_nb_ctrl_var(), sys_.get_nb_target_var(), sys_.get_horizon()) == (8, 8, 16, 600)
+    u0 = np.tile(np.array([0.1] * nb_ctrl_var), horizon - 1)
+    PSI = np.kron(primitives.build_psi_unitstep(horizon - 1, 2), np.identity(nb_ctrl_var))
+    cb = PythonCallbackMessage()
+    capsys.readouterr()
+    BatchILQRCP(sys_, PSI).solve(25, u0, True, cb)
+    _check_stream(capsys.readouterr().out.strip().splitlines(), g["solves"][0]["trace"])
+    X2, F_X2, U2, K2, k2, cost = ILQRRecursive(sys_).solve(u0.reshape((-1, nb_ctrl_var)), 10, True, True, cb)
+    _check_stream(capsys.readouterr().out.strip().splitlines(), g["solves"][1]["trace"])
+    X2 = np.asarray(X2)
+    assert X2.shape == (600, 8) and abs(X2[-1, -1] - 5.0) < 0.3 and abs(X2[300, -1] - 2.5) < 0.3  # the clock meets both continuous times
+
+
 def test_joint_space_tutorial(capsys):
     """JOINT_SPACE_SYS.ipynb (cells 4-15) with seeded targets (the notebook draws them unseeded, so its numbers cannot be pinned):
     the problem is linear-quadratic, so ILQRRecursive reaches the optimum in one iteration and then fails to improve -- the
