@@ -1,0 +1,111 @@
+"""Parity at BASELINE.json's full sizes (C3: B = 4096, T = 200, AL; C4: 8 x 4096 = 32768 instances of the time-augmented 2nd-order
+system; C5: B = 8192, T = 400, Batch-CP; BatchILQR at the tutorial shape), where running the oracle on every instance would take
+minutes: size-independent properties plus a sample of instances against the oracle.
+
+* instances are independent: a batch whose second half repeats the first gives bit-identical results for i and i + B/2, and a
+  64-instance batch cut out of it reproduces the big batch bit for bit (no result depends on the batch size, the position in a
+  wave or the workgroup an instance lands in);
+* the returned trajectory is the rollout of the returned controls (oracle dynamics), and for the recursive solver the returned
+  cost is the reference's cost of that trajectory (oracle cost function);
+* a seeded sample of instances agrees with the oracle in final cost within the north star's 1e-4 (median 1e-6)."""
+import numpy as np
+import pytest
+
+from tests.helpers import oracle_solve_instance, oracle_system_of_instance, orc, panda_segs, psi_of
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from ilqr_planner_amd import capi
+
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def _take(inp, idx):
+    out = dict(inp)
+    for k in ("q0", "dq0", "U0", "lambda0"):
+        if k in inp:
+            out[k] = np.ascontiguousarray(inp[k][idx])
+    out["targets"] = [np.ascontiguousarray(t[idx]) for t in inp["targets"]]
+    return out
+
+
+def _solve(ctx, cfg, desc, inp, B, nb_iter, solver):
+    from ilqr_planner_amd import workloads
+
+    p = workloads.load_batch(ctx, desc, inp, B)
+    if solver == "batch":
+        p.solve_batch(nb_iter, False)
+    elif solver == "batch_cp":
+        p.solve_batch_cp(psi_of(cfg["psi"], cfg["T"], p.dims.n_u), nb_iter, False)
+    else:
+        workloads.run_solver(p, cfg, nb_iter=nb_iter, early_stop=False)
+    out = dict(cost=p.cost(), U=p.U(), X=p.X(), iters=p.iters(), alpha=p.alpha(), trace=p.trace(nb_iter)[0])
+    p.close()
+    return out
+
+
+@pytest.mark.parametrize("cfg_name,B,nb_iter,solver", [("C3", 4096, 20, "al"), ("C4", 32768, 8, "recursive"), ("C5", 8192, 10, "batch_cp"),
+                                                       ("C2", 4096, 10, "batch")])
+def test_full_size_properties(ctx, cfg_name, B, nb_iter, solver):
+    from ilqr_planner_amd import workloads
+
+    cfg = workloads.config(cfg_name)
+    desc, inp = workloads.make_batch(ctx, cfg, B=B)
+    h = B // 2
+    inp = _take(inp, np.concatenate([np.arange(h), np.arange(h)]))  # second half = first half
+    big = _solve(ctx, cfg, desc, inp, B, nb_iter, solver)
+    fin = np.isfinite(big["cost"])
+    assert fin.mean() > (0.5 if cfg_name == "C4" else 0.999)  # the reference itself diverges on many C4 instances
+    # independence of the instances, bit for bit
+    np.testing.assert_array_equal(big["cost"][:h], big["cost"][h:])
+    np.testing.assert_array_equal(big["U"][:h], big["U"][h:])
+    np.testing.assert_array_equal(big["iters"][:h], big["iters"][h:])
+    rng = np.random.default_rng(7)
+    idx = np.sort(rng.choice(B, 61, replace=False))  # ragged: not a multiple of the wave size
+    desc_s, _ = workloads.make_batch(ctx, cfg, B=len(idx))
+    small = _solve(ctx, cfg, desc_s, _take(inp, idx), len(idx), nb_iter, solver)
+    np.testing.assert_array_equal(small["cost"], big["cost"][idx])
+    np.testing.assert_array_equal(small["U"], big["U"][idx])
+    np.testing.assert_array_equal(small["X"], big["X"][idx])
+    # the returned trajectory is the rollout of the returned controls; recursive solver: the returned cost is the cost of that trajectory
+    segs = panda_segs()
+    T = cfg["T"]
+    for i in idx[fin[idx]][:4]:
+        s = oracle_system_of_instance(cfg, inp, i, segs)
+        x = np.asarray(big["X"][i][0])
+        c = 0.0
+        for k in range(T - 1):
+            c += orc.cost(s, x, big["U"][i][k], k)
+            x = orc.step(s, x, big["U"][i][k])[0]
+            np.testing.assert_allclose(big["X"][i][k + 1], x, rtol=0, atol=1e-9 * max(1.0, np.abs(x).max()))
+        c += orc.cost(s, x, np.zeros(s.n_u), T - 1)
+        if solver == "recursive":
+            assert abs(c - big["cost"][i]) <= 1e-9 * max(abs(c), 1e-9)
+    # a sample against the oracle
+    sample = idx[:24] if solver != "batch" else idx[:3]  # the dense 693-column restatement takes ~10 s per instance
+    rel = []
+    for i in sample:
+        got = big["cost"][i]
+        if solver in ("batch", "batch_cp"):  # the batch solvers report the cost before each step: compare the last one
+            so = oracle_system_of_instance(cfg, inp, i, segs)
+            u0 = inp["U0"][i].reshape(-1)
+            r = orc.solve_batch(so, u0, nb_iter, False) if solver == "batch" else orc.solve_batch_cp(so, psi_of(cfg["psi"], T, 7), u0, nb_iter, False)
+            ref, got = r["trace_cost"][-1], big["trace"][i][nb_iter - 1]
+        else:
+            ref = oracle_solve_instance(cfg, inp, i, nb_iter, False, segs)["cost"]
+        if not np.isfinite(ref) or not np.isfinite(got):
+            continue
+        rel.append(abs(got - ref) / max(abs(ref), 1e-12))
+    rel = np.asarray(rel)
+    assert len(rel) >= len(sample) // 3
+    assert np.median(rel) <= 1e-6, f"median rel err {np.median(rel):.2e}"
+    # AL-iLQR over 20 iterations without early stop is a discontinuous map (active-set mask, accept-anyway line search): the oracle's
+    # own final cost moves by 1e-6..1e-1 under 1e-15 input perturbations on such instances (tests/test_gpu_parity.py shows it per
+    # instance); here only the share of the sample within the bound is asserted
+    share = 0.75 if solver == "al" else 0.85
+    assert (rel <= 1e-4).mean() >= share, f"{(rel > 1e-4).sum()} of {len(rel)} sampled instances outside 1e-4 (max {rel.max():.2e})"
