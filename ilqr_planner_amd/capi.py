@@ -64,6 +64,7 @@ class ProblemDesc(C.Structure):
         ("kp_frame_p", (C.c_double * 3) * MAX_KP),
         ("kp_has_Ru", C.c_int * MAX_KP),
         ("kp_Ru", (C.c_double * MAX_NU) * MAX_KP),
+        ("kp_joint", C.c_int * MAX_KP),
         ("limit_multiplicity", C.c_int),
         ("reg", C.c_double),
         ("alpha_floor", C.c_double),
@@ -160,7 +161,7 @@ def chain_from_urdf(urdf_text: str, base: str, tip: str, tool_rpy=None, tool_xyz
 
 
 def make_desc(*, kind, nb_deriv, horizon, dt, R_diag, chain, kp_timesteps, kp_Q, limits=None, kp_dist=None, kp_frames=None, kp_Ru=None,
-              limit_multiplicity=1) -> ProblemDesc:
+              limit_multiplicity=1, kp_joint=None) -> ProblemDesc:
     """chain: dict(seg_joint, seg_xyz, seg_R, seg_axis, dof); limits: dict(state_max, state_min, limit_weight, penalty) or None."""
     L = load()
     d = ProblemDesc()
@@ -192,10 +193,13 @@ def make_desc(*, kind, nb_deriv, horizon, dt, R_diag, chain, kp_timesteps, kp_Q,
     nq = dims.n_Q
     for k, (ts, Q) in enumerate(zip(kp_timesteps, kp_Q)):
         d.kp_timestep[k] = int(ts)
-        Q = _f64(Q, (nq, nq))
-        for a in range(nq):
-            for b in range(nq):
-                d.kp_Q[k][a * nq + b] = Q[a, b]
+        jk = bool(kp_joint and kp_joint[k])  # Angular(Time)Keypoint of a joint-space sub-system (hybrid sequence): n_x x n_x precision
+        d.kp_joint[k] = int(jk)
+        nqk = dims.n_x if jk else nq
+        Q = _f64(Q, (nqk, nqk))
+        for a in range(nqk):
+            for b in range(nqk):
+                d.kp_Q[k][a * nqk + b] = Q[a, b]
     d.limit_multiplicity = int(limit_multiplicity)  # SequentialSystem: number of sub-systems
     for k, fr in enumerate(kp_frames or []):  # 4x4 pose of the object frame of keypoint k's sub-system (TransformedSimulationInterface) or None
         if fr is not None:

@@ -827,6 +827,8 @@ SequentialSystem::SequentialSystem(const std::shared_ptr<sim::SimulationInterfac
     horizon_ = s0->getHorizon();
     nb_deriv_ = s0->getNbDeriv();
     kind_ = s0->kind();
+    for (auto& sy : systems_)  // a hybrid sequence runs as its PosOrn(Time) sub-system's kind (see lower())
+        if (sy->kind() != ILQR_SYS_JOINT && sy->kind() != ILQR_SYS_JOINT_TIME) { kind_ = sy->kind(); break; }
     x0_ = s0->getInitState();
     q0_ = r->getJointsPos();
     dq0_ = r->getJointsVel();
@@ -944,13 +946,25 @@ Mat SequentialSystem::getQMatrix(bool sparse) {
 void SequentialSystem::lower(ilqr_problem_desc* d) const {
     std::vector<ilqr_problem_desc> subs(systems_.size());
     for (size_t i = 0; i < systems_.size(); i++) systems_[i]->lower(&subs[i]);
-    *d = subs[0];
+    // Hybrid sequences (HYBRID_SYS*.ipynb): JointSpace(Time)PlannerSys sub-systems next to PosOrn(Time)PlannerSys ones.  The dynamics
+    // are the same (JointSpacePlannerSys.cpp:93-116 = PosOrnPlannerSys.cpp:114-138); the device problem is the PosOrn one and the
+    // keypoints of the joint-space sub-systems are flagged kp_joint (residual target - x, J = I).
+    auto is_joint = [](int k) { return k == ILQR_SYS_JOINT || k == ILQR_SYS_JOINT_TIME; };
+    auto is_time = [](int k) { return k == ILQR_SYS_POS_ORN_TIME || k == ILQR_SYS_JOINT_TIME; };
+    size_t base = 0;
+    for (size_t i = 0; i < subs.size(); i++)
+        if (!is_joint(subs[i].kind)) { base = i; break; }
+    *d = subs[base];
+    const bool hybrid = !is_joint(d->kind);
     if ((int)Rdiag.size() != nb_ctrl_var_) throw std::runtime_error("[System] RtDiag must have nb_ctrl_var entries");
     for (int i = 0; i < nb_ctrl_var_; i++) d->R_diag[i] = Rdiag[i];  // l_u = R u, l_uu = R use the sequential system's own Rt
     int n_lim = 0;
     for (size_t i = 0; i < subs.size(); i++) {
         const auto& a = subs[i];
-        if (a.kind != d->kind || a.dt != d->dt) throw std::runtime_error("[ilqr_hip] sub-systems of different kinds / dt cannot be lowered");
+        const bool mixed = a.kind != d->kind;
+        if (mixed && !(hybrid && is_joint(a.kind) && is_time(a.kind) == is_time(d->kind) && d->nb_deriv == 1 && a.dof == d->dof))
+            throw std::runtime_error("[ilqr_hip] these sub-system kinds cannot be lowered together (joint-space next to PosOrn needs nbDeriv = 1 and 7 joints)");
+        if (a.dt != d->dt) throw std::runtime_error("[ilqr_hip] sub-systems of different kinds / dt cannot be lowered");
         if (a.limits_set != d->limits_set) throw std::runtime_error("[ilqr_hip] sub-systems with and without limits cannot be lowered together");
         if (a.limits_set) {
             n_lim++;
@@ -974,6 +988,7 @@ void SequentialSystem::lower(ilqr_problem_desc* d) const {
         if (o > 0 && a.kp_timestep[k] == d->kp_timestep[o - 1])
             throw std::runtime_error("[ilqr_hip] two keypoints share a timestep: not supported on the device");
         d->kp_timestep[o] = a.kp_timestep[k];
+        d->kp_joint[o] = (hybrid && is_joint(a.kind)) ? 1 : 0;  // its kp_Q is n_x x n_x with leading dimension n_x already
         std::memcpy(d->kp_Q[o], a.kp_Q[k], sizeof(a.kp_Q[k]));
         d->kp_dist[o] = a.kp_dist[k];
         d->kp_pos_radius[o] = a.kp_pos_radius[k];

@@ -38,7 +38,7 @@ ILQR_DEV void limit_terms(const DevDesc& d, const double* x, double* Ld, double*
     UNR for (int i = 0; i < S::NX; i++) {
         Ld[i] = 0;
         q[i] = 0;
-        if (d.limits_set && d.lw[i] != 0) {
+        if (d.limits_set && d.batch_limits && d.lw[i] != 0) {
             if (x[i] > d.smax[i]) { q[i] = d.smax[i] - x[i]; Ld[i] = d.penalty; }
             else if (x[i] < d.smin[i]) { q[i] = d.smin[i] - x[i]; Ld[i] = d.penalty; }
         }

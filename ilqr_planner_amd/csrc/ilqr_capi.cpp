@@ -246,6 +246,7 @@ static int lower_desc(ilqr_ctx* c, const ilqr_problem_desc& d, int B, int Bp, De
         h.limits_set = d.limits_set;
         h.penalty = d.penalty * mult;
         h.pen_xx = d.penalty * d.penalty * mult;
+        h.batch_limits = d.limit_multiplicity > 1 ? 0 : 1;
     }
     for (int i = 0; i < dm.n_x; i++) { h.smax[i] = d.state_max[i]; h.smin[i] = d.state_min[i]; h.lw[i] = d.limit_weight[i]; }
     if (d.n_kp < 0 || d.n_kp > ILQR_MAX_KP) return fail(c, "bad n_kp");
@@ -254,7 +255,12 @@ static int lower_desc(ilqr_ctx* c, const ilqr_problem_desc& d, int B, int Bp, De
         if (d.kp_timestep[k] < 0 || d.kp_timestep[k] >= d.horizon) return fail(c, "keypoint timestep outside the horizon");
         if (k > 0 && d.kp_timestep[k] <= d.kp_timestep[k - 1]) return fail(c, "keypoint timesteps must be unique and ascending");
         h.kp_t[k] = d.kp_timestep[k];
-        for (int i = 0; i < dm.n_Q * dm.n_Q; i++) h.kp_Q[k][i] = d.kp_Q[k][i];
+        if (d.kp_joint[k] && !((d.kind == ILQR_SYS_POS_ORN || d.kind == ILQR_SYS_POS_ORN_TIME) && d.nb_deriv == 1))
+            return fail(c, "kp_joint is for PosOrn / PosOrnTime systems with nb_deriv = 1 (a joint-space system needs no flag)");
+        if (d.kp_joint[k] && (d.kp_dist[k] || d.kp_has_frame[k])) return fail(c, "a joint-space keypoint has no dead zone and no object frame");
+        h.kp_joint[k] = d.kp_joint[k];
+        const int nqk = d.kp_joint[k] ? dm.n_x : dm.n_Q;
+        for (int i = 0; i < nqk * nqk; i++) h.kp_Q[k][i] = d.kp_Q[k][i];
         h.kp_dist[k] = d.kp_dist[k];
         h.kp_frame[k] = d.kp_has_frame[k];
         for (int i = 0; i < 9; i++) h.kp_fR[k][i] = d.kp_frame_R[k][i];
@@ -495,7 +501,7 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
     FwdArgs f;
     std::memset(&f, 0, sizeof(f));
     f.line_search = line_search; f.early_stop = early_stop; f.nb_iter = nb_iter; f.penalty_roll = penalty; f.n_alpha = n_alpha; f.al = al ? 1 : 0; f.n_kp = p->desc.n_kp;
-    for (int k = 0; k < p->desc.n_kp; k++) f.kp_ext |= p->desc.kp_dist[k] | p->desc.kp_has_frame[k] | p->desc.kp_has_Ru[k];
+    for (int k = 0; k < p->desc.n_kp; k++) f.kp_ext |= p->desc.kp_dist[k] | p->desc.kp_has_frame[k] | p->desc.kp_has_Ru[k] | p->desc.kp_joint[k];
     {
         ProfScope ps(c, ILQR_PROF_ROLLOUT);
         if (path != 1 && init_lti_supported(kind, nd)) {

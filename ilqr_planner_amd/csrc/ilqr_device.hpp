@@ -49,6 +49,10 @@ struct DevDesc {
     double kp_fR[MAX_KP][9], kp_fp[MAX_KP][3];
     int kp_has_Ru[MAX_KP];             // control penalty of the keypoint's own sub-system (SequentialSystem)
     double kp_Ru[MAX_KP][MAX_NU];
+    int kp_joint[MAX_KP];              // Angular(Time)Keypoint of a joint-space sub-system inside a PosOrn(Time) system (hybrid SequentialSystem,
+                                       // nb_deriv = 1): residual target - x, J = I, precision n_x x n_x (leading dimension n_x)
+    int batch_limits;                  // 0: the batch solvers see no limit terms (sequence of sub-systems: SequentialSystem does not override
+                                       // fpBatch, and the sequence object itself has no limits); 1: plain system
     double pen_xx;                     // penalty^2 x limit multiplicity (l_xx of a violated limit); `penalty` holds penalty x multiplicity
 };
 
@@ -387,6 +391,24 @@ ILQR_DEV double limit_cost(const DevDesc& d, const double* x) {
 // instantiation the hot kernels use when the descriptor has none of those (FwdArgs::kp_ext)
 template <class S, bool EXT = true>
 ILQR_DEV double kp_cost(const DevDesc& d, int kpi, const double* tg, const double* x, const double* u) {
+    if (EXT && !S::JOINT && S::ND == 1 && d.kp_joint[kpi]) {  // joint-space keypoint of a hybrid sequence: e = target - x
+        constexpr int NJ = S::NX;
+        const double* Q = d.kp_Q[kpi];
+        double c = 0;
+#pragma unroll
+        for (int i = 0; i < NJ; i++) {
+            double qe = 0;
+#pragma unroll
+            for (int j = 0; j < NJ; j++) qe += Q[i * NJ + j] * (tg[j] - x[j]);
+            c += (tg[i] - x[i]) * qe;
+        }
+        double ru = 0;
+        if (u) {
+#pragma unroll
+            for (int i = 0; i < S::NU; i++) ru += u[i] * (d.kp_has_Ru[kpi] ? d.kp_Ru[kpi][i] : d.R_diag[i]) * u[i];
+        }
+        return c + ru;
+    }
     double fxv[S::NF], e[S::NQ];
     fx_of<S, false>(d, x, fxv, nullptr, EXT ? kpi : -1);
     kp_diff<S>(tg, fxv, e);

@@ -45,7 +45,15 @@ ILQR_DEV void stage_derivs(const DevDesc& d, const Bufs& a, int b, const double*
         lx[i] = 0;
         UNR for (int j = 0; j < NX; j++) lxx[i][j] = 0;
     }
-    if (kpi >= 0 && S::JOINT) {  // J = I: l_x = -Q e, l_xx = Q
+    if (kpi >= 0 && !S::JOINT && EXT && S::ND == 1 && d.kp_joint[kpi]) {  // joint-space keypoint of a hybrid sequence (J = I, n_x x n_x precision)
+        const double* Q = d.kp_Q[kpi];
+        UNR for (int i = 0; i < NX; i++) {
+            double s = 0;
+            UNR for (int j = 0; j < NX; j++) s += Q[i * NX + j] * (AT(a.kp_tg, kpi * NF + j, b) - x[j]);
+            lx[i] += -1 * s;
+            UNR for (int j = 0; j < NX; j++) lxx[i][j] += Q[i * NX + j];
+        }
+    } else if (kpi >= 0 && S::JOINT) {  // J = I: l_x = -Q e, l_xx = Q
         double e[NQ], tg[NF];
         UNR for (int i = 0; i < NF; i++) tg[i] = AT(a.kp_tg, kpi * NF + i, b);
         kp_diff<S>(tg, x, e);

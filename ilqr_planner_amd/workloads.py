@@ -57,6 +57,12 @@ def config(name: str):
         "C4t1": dict(kind=capi.SYS_POS_ORN_TIME, nb_deriv=1, T=100, dt=None, B=256, seed=7, Qdiag=[P + [0], P + [.1]], ctimes=[2.0, 5.0],
                      solver="recursive", nb_iter=14),
         # Batch-CP on the time-augmented 2nd-order system (the C4 system shape), sawtooth x controls + unit-step x sqrt(dt)
+        # hybrid sequences (HYBRID_SYS.ipynb, HYBRID_SYS_TIME.ipynb): a joint-space via point (Angular(Time)Keypoint of a JointSpace(Time)PlannerSys
+        # sub-system, own control penalty 1e-3) followed by a pose goal of a PosOrn(Time)PlannerSys sub-system, limits counted twice
+        "C2h": dict(kind=capi.SYS_POS_ORN, nb_deriv=1, T=100, dt=0.05, B=256, seed=12, Qdiag=[[1] * 7, P], solver="recursive", nb_iter=12, hybrid=True,
+                    psi=dict(kind="unitstep", K=2)),
+        "C4h": dict(kind=capi.SYS_POS_ORN_TIME, nb_deriv=1, T=100, dt=None, B=128, seed=13, Qdiag=[[1] * 7 + [0], P + [.1]], ctimes=[2.5, 5.0],
+                    solver="recursive", nb_iter=12, hybrid=True),
         "C4cp": dict(kind=capi.SYS_POS_ORN_TIME, nb_deriv=2, T=50, dt=None, B=64, seed=5, Qdiag=[P + V + [.1], P + V + [.1]],
                      ctimes=[2.5, 5.0], solver="batch_cp", nb_iter=8, psi=dict(kind="sawtooth+unitstep_dt", K=2)),
     }
@@ -87,9 +93,11 @@ def make_batch(ctx: capi.Context, cfg: dict, B: int | None = None, seed: int | N
     smax[:dof], smin[:dof], w[:dof] = qmax, qmin, 1
     if nd == 2:
         smax[dof:2 * dof], smin[dof:2 * dof], w[dof:2 * dof] = 10.0, -10.0, 1
+    hyb = bool(cfg.get("hybrid"))
     desc = capi.make_desc(kind=kind, nb_deriv=nd, horizon=T, dt=cfg["dt"], R_diag=[1e-5] * nu, chain=chain, kp_timesteps=kp_t,
                           kp_Q=[np.diag(q) for q in cfg["Qdiag"]], limits=dict(state_max=smax, state_min=smin, limit_weight=w, penalty=1.0),
-                          kp_dist=cfg.get("kp_dist"))
+                          kp_dist=cfg.get("kp_dist"), kp_joint=[1, 0] if hyb else None, kp_Ru=[[1e-3] * nu, [1e-5] * nu] if hyb else None,
+                          limit_multiplicity=2 if hyb else 1)
     q0 = np.clip(Q0_TUT[None, :] + rng.uniform(-0.3, 0.3, (B, dof)), lo, up)
     targets = []
     for i in range(2):
@@ -100,6 +108,8 @@ def make_batch(ctx: capi.Context, cfg: dict, B: int | None = None, seed: int | N
             cols += [np.zeros((B, 3)), np.zeros((B, 4))]
         if tm:
             cols += [np.full((B, 1), cfg["ctimes"][i])]
+        if hyb and i == 0:  # the via point is a joint configuration (+ its continuous time)
+            cols = [qr] + ([np.full((B, 1), cfg["ctimes"][0])] if tm else [])
         targets.append(np.ascontiguousarray(np.hstack(cols)))
     U0 = np.zeros((B, T - 1, nu))
     if tm:

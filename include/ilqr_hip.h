@@ -96,12 +96,19 @@ typedef struct {
      * kp_has_frame[k] = 0: base frame.  sys::SequentialSystem (src/system/SequentialSystem.cpp:78-168) sums the costs of its
      * sub-systems: every keypoint carries the control penalty of its own sub-system (kp_has_Ru / kp_Ru; the sequential
      * system's own Rt stays in R_diag for l_u, l_uu) and the limit terms are added once per sub-system (limit_multiplicity;
-     * 0 = 1).  Sub-systems whose keypoints share a timestep are not lowered. */
+     * 0 = 1).  Sub-systems whose keypoints share a timestep are not lowered.  With limit_multiplicity > 1 the batch solvers
+     * (ilqr_solve_batch_cp, ilqr_solve_batch) apply NO limit terms: the reference's SequentialSystem does not override fpBatch, which
+     * then runs on the sequence object itself, constructed without limits (SequentialSystem.cpp:12-18). */
     int kp_has_frame[ILQR_MAX_KP];
     double kp_frame_R[ILQR_MAX_KP][9]; /* row-major */
     double kp_frame_p[ILQR_MAX_KP][3];
     int kp_has_Ru[ILQR_MAX_KP];
     double kp_Ru[ILQR_MAX_KP][ILQR_MAX_NU];
+    /* Hybrid sequences (HYBRID_SYS*.ipynb): a SequentialSystem may mix a JointSpace(Time)PlannerSys with PosOrn(Time)PlannerSys
+     * sub-systems (same state and controls, nb_deriv = 1).  kp_joint[k] = 1 marks keypoint k as the Angular(Time)Keypoint of the
+     * joint-space sub-system: target = joint vector (+ continuous time) in the keypoint's n_f slots, residual target - x, J = I
+     * (src/system/JointSpacePlannerSys.cpp:77-81), precision n_x x n_x in kp_Q[k] with leading dimension n_x. */
+    int kp_joint[ILQR_MAX_KP];
     int limit_multiplicity;
     double reg;          /* 1e-6 */
     double alpha_floor;  /* 1e-3 */

@@ -306,6 +306,14 @@ static void fx_jac_frame(const orc_system* s, const orc_keypoint* kp, const doub
         }
         return;
     }
+    if (kp && kp->joint) { /* keypoint of a joint-space sub-system of a hybrid SequentialSystem: that sub-system's f(x) = x, J = I */
+        if (fx) memcpy(fx, x, sizeof(double) * s->n_x);
+        if (J) {
+            memset(J, 0, sizeof(double) * s->n_x * s->n_x);
+            for (int i = 0; i < s->n_x; i++) J[i * s->n_x + i] = 1;
+        }
+        return;
+    }
     double p[3], quat[4], Jac[6 * ORC_MAX_DOF], dx[3], w[3], dq0[ORC_MAX_DOF] = {0};
     const double* dq = (nd == 2) ? x + dof : dq0;
     orc_fk(&s->chain, x, dq, p, quat, Jac, dx, w);
@@ -367,8 +375,9 @@ void orc_get_fx_jac(const orc_system* s, const double* x, double* fx, double* J)
 /* PosOrnKeypoint::diff (PosOrnKeypoint.cpp:24-45), SpacetimeKeypoint::diff (SpacetimeKeypoint.cpp:19-25) */
 void orc_kp_diff(const orc_system* s, const orc_keypoint* kp, const double* fx, double* e) {
     int nd = s->nb_deriv, tm = ORC_IS_TM(s->kind);
-    if (ORC_IS_JOINT(s->kind)) { /* AngularKeypoint::diff (AngularKeypoint.cpp:24-27), AngularTimeKeypoint::diff (:22-27): target - state, t* - t last */
-        for (int i = 0; i < s->n_Q; i++) e[i] = kp->jt[i] - fx[i];
+    if (ORC_IS_JOINT(s->kind) || kp->joint) { /* AngularKeypoint::diff (AngularKeypoint.cpp:24-27), AngularTimeKeypoint::diff (:22-27): target - state, t* - t last */
+        const int n = kp->joint ? s->n_x : s->n_Q;
+        for (int i = 0; i < n; i++) e[i] = kp->jt[i] - fx[i];
         return;
     }
     int nst = 7 * nd;
@@ -404,6 +413,15 @@ void orc_kp_diff(const orc_system* s, const orc_keypoint* kp, const double* fx, 
     }
 }
 
+/* residual size of a keypoint, and the largest one of the system (row stride of per-step J / e buffers) */
+static int kp_nq(const orc_system* s, const orc_keypoint* kp) { return (kp && kp->joint) ? s->n_x : s->n_Q; }
+static int nq_stride(const orc_system* s) {
+    int n = s->n_Q;
+    for (int i = 0; i < s->n_kp; i++)
+        if (s->kp[i].joint && s->n_x > n) n = s->n_x;
+    return n;
+}
+
 static const orc_keypoint* find_kp(const orc_system* s, int k) { /* System.cpp:96-101; later duplicates win in the map */
     const orc_keypoint* r = NULL;
     for (int i = 0; i < s->n_kp; i++)
@@ -431,7 +449,7 @@ double orc_cost(const orc_system* s, const double* x, const double* u, int k) {
         double fx[ORC_MAX_NF], e[ORC_MAX_NQ], Qe[ORC_MAX_NQ];
         fx_jac_frame(s, kp, x, fx, NULL);
         orc_kp_diff(s, kp, fx, e);
-        int nq = s->n_Q;
+        int nq = kp_nq(s, kp);
         for (int i = 0; i < nq; i++) Qe[i] = dot(kp->Q + i * nq, e, nq);
         double ru = 0;
         const double* Rk = kp->has_Ru ? kp->Ru : s->R_diag;
@@ -449,9 +467,10 @@ double orc_cost(const orc_system* s, const double* x, const double* u, int k) {
 
 /* System::cost_x, System.cpp:248-272:  -J^T Q e - L^T q */
 void orc_cost_x(const orc_system* s, const double* x, int k, double* lx) {
-    int nx = s->n_x, nq = s->n_Q;
+    int nx = s->n_x;
     memset(lx, 0, sizeof(double) * nx);
     const orc_keypoint* kp = find_kp(s, k);
+    const int nq = kp_nq(s, kp);
     if (kp) {
         double fx[ORC_MAX_NF], J[ORC_MAX_NQ * ORC_MAX_NX], e[ORC_MAX_NQ], Qe[ORC_MAX_NQ];
         fx_jac_frame(s, kp, x, fx, J);
@@ -472,9 +491,10 @@ void orc_cost_x(const orc_system* s, const double* x, int k, double* lx) {
 
 /* System::cost_xx, System.cpp:286-308:  J^T Q J + L^T L */
 void orc_cost_xx(const orc_system* s, const double* x, int k, double* lxx) {
-    int nx = s->n_x, nq = s->n_Q;
+    int nx = s->n_x;
     memset(lxx, 0, sizeof(double) * nx * nx);
     const orc_keypoint* kp = find_kp(s, k);
+    const int nq = kp_nq(s, kp);
     if (kp) {
         double J[ORC_MAX_NQ * ORC_MAX_NX], JtQ[ORC_MAX_NX * ORC_MAX_NQ], JtQJ[ORC_MAX_NX * ORC_MAX_NX];
         fx_jac_frame(s, kp, x, NULL, J);
@@ -768,7 +788,7 @@ typedef struct {
 
 /* System::fpBatch, System.cpp:181-211 with forwardPassWithLimits :144-161 (limits on the PRE-step state) */
 static void fp_batch_run(const orc_system* s, const double* u, fp_batch* f) {
-    const int T = s->T, nx = s->n_x, nu = s->n_u, nf = s->n_f, nq = s->n_Q;
+    const int T = s->T, nx = s->n_x, nu = s->n_u, nf = s->n_f, nq = nq_stride(s);
     double x[ORC_MAX_NX], xn[ORC_MAX_NX];
     init_state(s, x);
     memset(f->qL, 0, sizeof(double) * T * nx);
@@ -780,10 +800,13 @@ static void fp_batch_run(const orc_system* s, const double* u, fp_batch* f) {
     for (int i = 0; i < T - 1; i++) {
         orc_step(s, x, u + (size_t)i * nu, xn, f->fX + (size_t)(i + 1) * nf, f->A + (size_t)(i + 1) * nx * nx,
                  f->B + (size_t)(i + 1) * nx * nu, f->J + (size_t)(i + 1) * nq * nx);
-        limits(s, x, f->L + (size_t)(i + 1) * nx, f->qL + (size_t)(i + 1) * nx);
+        /* a SequentialSystem does not override fpBatch / forwardPassWithLimits (SequentialSystem.h:31-41): they run on the sequence
+         * object itself, which is built by the constructor WITHOUT limits (SequentialSystem.cpp:12-18: limits_set_ = false), so the batch
+         * solvers see no limit terms at all -- unlike ILQRRecursive, whose cost, cost_x, cost_xx are the sums over the sub-systems */
+        if (!(s->lim_mult > 1)) limits(s, x, f->L + (size_t)(i + 1) * nx, f->qL + (size_t)(i + 1) * nx);
         {   /* a keypoint whose system works in an object frame (TransformedSimulationInterface): f(x) and J in that frame */
             const orc_keypoint* kf = find_kp(s, i + 1);
-            if (kf && kf->has_frame) fx_jac_frame(s, kf, xn, f->fX + (size_t)(i + 1) * nf, f->J + (size_t)(i + 1) * nq * nx);
+            if (kf && (kf->has_frame || kf->joint)) fx_jac_frame(s, kf, xn, f->fX + (size_t)(i + 1) * nf, f->J + (size_t)(i + 1) * nq * nx);
         }
         memcpy(x, xn, sizeof(x));
     }
@@ -791,16 +814,17 @@ static void fp_batch_run(const orc_system* s, const double* u, fp_batch* f) {
 
 static double cp_cost(const orc_system* s, const fp_batch* f, const double* u, double* e_out) {
     /* e'Qe + u'Ru + ql'L ql over keypoint rows: BatchILQRCP.cpp:135,150 */
-    const int T = s->T, nx = s->n_x, nu = s->n_u, nf = s->n_f, nq = s->n_Q;
+    const int T = s->T, nx = s->n_x, nu = s->n_u, nf = s->n_f, nqs = nq_stride(s);
     double c_e = 0, c_u = 0, c_l = 0;
     for (int t = 0; t < s->n_kp; t++) {
         const orc_keypoint* kp = &s->kp[t];
         int ts = kp->timestep;
+        const int nq = kp_nq(s, kp);
         double e[ORC_MAX_NQ], Qe[ORC_MAX_NQ];
         orc_kp_diff(s, find_kp(s, ts), f->fX + (size_t)ts * nf, e); /* System::diff looks the keypoint up in the map */
         for (int i = 0; i < nq; i++) Qe[i] = dot(kp->Q + i * nq, e, nq);
         c_e += dot(e, Qe, nq);
-        if (e_out) memcpy(e_out + (size_t)t * nq, e, sizeof(double) * nq);
+        if (e_out) memcpy(e_out + (size_t)t * nqs, e, sizeof(double) * nq);
         for (int i = 0; i < nx; i++) c_l += f->qL[(size_t)ts * nx + i] * f->L[(size_t)ts * nx + i] * f->qL[(size_t)ts * nx + i];
     }
     for (int k = 0; k < T - 1; k++)
@@ -810,7 +834,7 @@ static double cp_cost(const orc_system* s, const fp_batch* f, const double* u, d
 
 int orc_solve_batch_cp(const orc_system* s, const double* psi, int Kw, double* u, int nb_iter, int early_stop,
                        double* trace_cost, double* trace_alpha) {
-    const int T = s->T, nx = s->n_x, nu = s->n_u, nf = s->n_f, nq = s->n_Q, nkp = s->n_kp;
+    const int T = s->T, nx = s->n_x, nu = s->n_u, nf = s->n_f, nq = nq_stride(s), nkp = s->n_kp;
     const int NU = (T - 1) * nu;
     fp_batch f, ft;
     fp_batch* fs[2] = {&f, &ft};
@@ -869,10 +893,11 @@ int orc_solve_batch_cp(const orc_system* s, const double* psi, int Kw, double* u
             const orc_keypoint* kp = &s->kp[t];
             int ts = kp->timestep;
             const double* Jt = f.J + (size_t)ts * nq * nx;
+            const int nqk = kp_nq(s, kp);
             double JtQ[ORC_MAX_NX * ORC_MAX_NQ], W[ORC_MAX_NX * ORC_MAX_NX], r[ORC_MAX_NX];
-            mtm(JtQ, Jt, kp->Q, nq, nx, nq);
-            mm(W, JtQ, Jt, nx, nq, nx);
-            mm(r, JtQ, e + (size_t)t * nq, nx, nq, 1);
+            mtm(JtQ, Jt, kp->Q, nqk, nx, nqk);
+            mm(W, JtQ, Jt, nx, nqk, nx);
+            mm(r, JtQ, e + (size_t)t * nq, nx, nqk, 1);
             for (int i = 0; i < nx; i++) {
                 W[i * nx + i] += f.L[(size_t)ts * nx + i];
                 r[i] += f.L[(size_t)ts * nx + i] * f.qL[(size_t)ts * nx + i];

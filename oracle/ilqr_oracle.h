@@ -66,6 +66,10 @@ typedef struct {
     int has_Ru;
     double Ru[ORC_MAX_NU];
     double jt[ORC_MAX_NX];      /* AngularKeypoint target (joint space, AngularKeypoint.cpp:15-27) */
+    /* 1 = an Angular(Time)Keypoint inside a PosOrn(Time) system: the keypoint of a JointSpace(Time)PlannerSys sub-system of a
+     * SequentialSystem (HYBRID_SYS*.ipynb; nb_deriv = 1).  Its sub-system has f(x) = x, J = I (JointSpacePlannerSys.cpp:77-81), so its
+     * residual is jt - x with an n_x x n_x precision (stored in Q with leading dimension n_x). */
+    int joint;
 } orc_keypoint;
 
 typedef struct {

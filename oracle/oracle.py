@@ -53,6 +53,7 @@ class Keypoint(C.Structure):
         ("has_Ru", C.c_int),
         ("Ru", C.c_double * MAX_NU),
         ("jt", C.c_double * MAX_NX),
+        ("joint", C.c_int),
     ]
 
 
@@ -270,10 +271,12 @@ def make_system(segs, kind, nb_deriv, T, dt, R_diag, keypoints, q0, dq0=None, qM
     for i, k in enumerate(kps):
         kp = s.kp[i]
         kp.timestep = int(k["timestep"])
-        if kind in (SYS_JOINT, SYS_JOINT_TIME):  # AngularKeypoint / AngularTimeKeypoint: joint vector (+ continuous time last)
-            tgt = list(k["target"]) + ([float(k["ctime"])] if kind == SYS_JOINT_TIME else [])
+        joint_kp = bool(k.get("joint"))  # Angular(Time)Keypoint of a joint-space sub-system inside a PosOrn(Time) system (hybrid sequence)
+        if kind in (SYS_JOINT, SYS_JOINT_TIME) or joint_kp:  # AngularKeypoint / AngularTimeKeypoint: joint vector (+ continuous time last)
+            tgt = list(k["target"]) + ([float(k["ctime"])] if kind in (SYS_JOINT_TIME, SYS_POS_ORN_TIME) else [])
             for j, v in enumerate(tgt):
                 kp.jt[j] = float(v)
+            kp.joint = 1 if joint_kp else 0
         else:
             for j in range(3):
                 kp.pos[j] = k["pos"][j]
@@ -282,10 +285,11 @@ def make_system(segs, kind, nb_deriv, T, dt, R_diag, keypoints, q0, dq0=None, qM
                 kp.orn[j] = k["orn"][j]
                 kp.dorn[j] = k.get("dorn", [0, 0, 0, 0])[j]
         kp.ctime = float(k.get("ctime", 0.0))
-        Q = _arr(k["Q"]).reshape(nq, nq)
-        for a in range(nq):
-            for b in range(nq):
-                kp.Q[a * nq + b] = Q[a, b]
+        nqk = s.n_x if joint_kp else nq
+        Q = _arr(k["Q"]).reshape(nqk, nqk)
+        for a in range(nqk):
+            for b in range(nqk):
+                kp.Q[a * nqk + b] = Q[a, b]
         if k.get("frame") is not None:  # 4x4 pose of the frame the keypoint's sub-system works in (TransformedSimulationInterface)
             Tm = _arr(k["frame"]).reshape(4, 4)
             kp.has_frame = 1

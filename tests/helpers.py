@@ -105,6 +105,14 @@ def oracle_system_of_instance(cfg, inp, i, segs=None):
             d["ctime"] = tg[-1]
         if cfg.get("kp_dist") and cfg["kp_dist"][k] is not None:
             d["dist"] = cfg["kp_dist"][k]  # PosOrnKeypointDistFunct
+        if cfg.get("hybrid"):  # workloads "C2h"/"C4h": joint-space via point of a JointSpace(Time)PlannerSys sub-system, then a pose goal
+            nu_ = 7 + (1 if tm else 0)
+            if k == 0:
+                d = dict(timestep=ts, joint=True, target=tg[:7], Q=np.diag(cfg["Qdiag"][k]), Ru=[1e-3] * nu_)
+                if tm:
+                    d["ctime"] = tg[-1]
+            else:
+                d["Ru"] = [1e-5] * nu_
         kps.append(d)
     dof = 7
     lim = inp["limits"]
@@ -113,7 +121,7 @@ def oracle_system_of_instance(cfg, inp, i, segs=None):
     dqMin = lim["state_min"][dof:2 * dof] if nd == 2 else None
     nu = dof + (1 if tm else 0)
     return orc.make_system(segs, orc.SYS_POS_ORN_TIME if tm else orc.SYS_POS_ORN, nd, cfg["T"], cfg["dt"], [1e-5] * nu, kps,
-                           inp["q0"][i], inp["dq0"][i], qMax, qMin, dqMax, dqMin)
+                           inp["q0"][i], inp["dq0"][i], qMax, qMin, dqMax, dqMin, lim_mult=2 if cfg.get("hybrid") else 1)
 
 
 def oracle_solve_instance(cfg, inp, i, nb_iter, early_stop, segs=None):

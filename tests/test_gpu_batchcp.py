@@ -66,6 +66,37 @@ def test_cp_random_batch_vs_oracle(ctx, cfg_name, B, nb_iter):
     p.close()
 
 
+def test_cp_on_a_sequence_ignores_limits(ctx):
+    """Batch-CP on a (hybrid) SequentialSystem: joint-space via point + pose goal, and NO limit terms although the sub-systems have
+    violated limits -- SequentialSystem does not override fpBatch, which runs on the sequence object built without limits
+    (SequentialSystem.cpp:12-18).  The same batch with limit_multiplicity = 1 (a plain system) does count them."""
+    from ilqr_planner_amd import workloads
+
+    cfg = workloads.config("C2h")
+    B, nb_iter = 16, 5
+    desc, inp = workloads.make_batch(ctx, cfg, B=B, limits="urdf")
+    inp["U0"] = inp["U0"] + 0.8  # drives joints over their limits
+    psi = psi_of(cfg["psi"], cfg["T"], 7)
+    p = workloads.load_batch(ctx, desc, inp, B)
+    p.solve_batch_cp(psi, nb_iter, False)
+    ct, at = p.trace(nb_iter)
+    U = p.U()
+    p.close()
+    for i in range(B):
+        s = oracle_system_of_instance(cfg, inp, i)
+        r = orc.solve_batch_cp(s, psi, inp["U0"][i].reshape(-1), nb_iter, False)
+        np.testing.assert_allclose(ct[i][0], r["trace_cost"][0], rtol=1e-12)
+        if np.array_equal(at[i], r["trace_alpha"]):
+            np.testing.assert_allclose(ct[i], r["trace_cost"], rtol=1e-4)
+            np.testing.assert_allclose(U[i].reshape(-1), r["u"], rtol=0, atol=1e-4 * max(1.0, np.abs(r["u"]).max()))
+    desc.limit_multiplicity = 1
+    p = workloads.load_batch(ctx, desc, inp, B)
+    p.solve_batch_cp(psi, 1, False)
+    c_plain = p.trace(1)[0][:, 0]
+    p.close()
+    assert np.all(c_plain > ct[:, 0] + 1e-3)  # the limit terms of the violated joints
+
+
 def test_cp_errors(ctx):
     from ilqr_planner_amd import workloads
 

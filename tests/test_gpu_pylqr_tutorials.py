@@ -353,6 +353,99 @@ def test_multi_sys_time_tutorial(capsys):
     assert X2.shape == (600, 8) and abs(X2[-1, -1] - 5.0) < 0.3 and abs(X2[300, -1] - 2.5) < 0.3  # the clock meets both continuous times
 
 
+def _oracle_stream(r):
+    return [[None if np.isnan(c) else float("%.6g" % c), float("%.6g" % a)] for c, a in zip(r["trace_cost"], r["trace_alpha"])]
+
+
+def test_hybrid_sys_tutorial(capsys):
+    """HYBRID_SYS.ipynb (cells 2-17): SequentialSystem of a JointSpacePlannerSys (joint-space via point, R = 1e-3) and a PosOrnPlannerSys
+    (pose goal, R = 1e-3), the sequence's own R = 1e-6.  The notebook draws the joint target unseeded, so the stream is checked
+    against the oracle on a seeded target instead of the stored output."""
+    from PyLQR.sim import KDLRobot
+    from PyLQR.solver import BatchILQRCP, ILQRRecursive
+    from PyLQR.system import AngularKeypoint, JointSpacePlannerSys, PosOrnKeypoint, PosOrnPlannerSys, SequentialSystem
+    from PyLQR.utils import PythonCallbackMessage, primitives
+    from tests.helpers import orc, panda_segs
+
+    g = golden()["cases"]["POS_ORN_SYS"]["problem"]
+    dof, nb_ctrl_var, horizon, dt = 7, 7, 500, 0.01
+    q0, dq0 = g["q0"], [0] * dof
+    qMax = np.array([2.8973, 1.7628, 2.8973, -0.0698, 2.8973, 3.7525, 2.8973])
+    qMin = np.array([-2.8973, -1.7628, -2.8973, -3.0718, -2.8973, -0.0175, -2.8973])
+    rbt = KDLRobot(URDF, "panda_link0", "panda_tip", q0, dq0)
+    target_1 = np.random.default_rng(21).uniform(qMin, qMax)
+    kp1 = AngularKeypoint(target_1, np.identity(dof), horizon // 2 - 1)
+    sys1 = JointSpacePlannerSys(rbt, [kp1], [1e-3] * nb_ctrl_var, qMax, qMin, horizon, 1, dt)
+    k2 = g["keypoints"][1]
+    kp2 = PosOrnKeypoint(np.array(k2["pos"]), np.array(k2["orn"]), np.diag(k2["Qdiag"]), horizon - 1)
+    sys2 = PosOrnPlannerSys(rbt, [kp2], (np.ones(nb_ctrl_var) * 1e-3).tolist(), qMax, qMin, horizon, 1, dt)
+    sys_ = SequentialSystem(rbt, [sys1, sys2], [1e-6] * nb_ctrl_var, horizon, 1)
+    assert (sys_.get_nb_state_var(), sys_.get_nb_ctrl_var(), sys_.get_nb_target_var(), sys_.get_horizon()) == (7, 7, 14, 500)
+    so = orc.make_system(panda_segs(), orc.SYS_POS_ORN, 1, horizon, dt, [1e-6] * 7, [
+        dict(timestep=horizon // 2 - 1, joint=True, target=target_1, Q=np.identity(7), Ru=[1e-3] * 7),
+        dict(timestep=horizon - 1, pos=k2["pos"], orn=k2["orn"], Q=np.diag(k2["Qdiag"]), Ru=[1e-3] * 7)], q0, dq0, qMax, qMin, lim_mult=2)
+    u0 = np.zeros((horizon - 1) * nb_ctrl_var)
+    PSI = np.kron(primitives.build_psi_unitstep(horizon - 1, 2), np.identity(nb_ctrl_var))
+    cb = PythonCallbackMessage()
+    capsys.readouterr()
+    U1 = BatchILQRCP(sys_, PSI).solve(25, u0, True, cb)
+    _check_stream(capsys.readouterr().out.strip().splitlines(), _oracle_stream(orc.solve_batch_cp(so, PSI, u0, 25, True)))
+    X2, F_X2, U2, K2, k2_, cost = ILQRRecursive(sys_).solve(u0.reshape((-1, nb_ctrl_var)), 10, True, True, cb)
+    _check_stream(capsys.readouterr().out.strip().splitlines(), _oracle_stream(orc.solve_recursive(so, u0, 10, True, True)))
+    X2 = np.asarray(X2)
+    np.testing.assert_allclose(X2[horizon // 2 - 1], target_1, atol=6e-2)  # through the joint-space via point ...
+    rbt.set_conf(q0, dq0, True)
+    for u in np.asarray(U2):
+        rbt.send_vel(dt, u, True)
+    np.testing.assert_allclose(rbt.get_ee_pos(), k2["pos"], atol=2e-2)     # ... to the pose goal
+    # the host evaluation API of the sequence stacks [x ; pose] and [I ; J]
+    fx, J = sys_.get_fx_jac(X2[10])
+    assert len(fx) == 14 and np.asarray(J).shape == (13, 7)
+    np.testing.assert_array_equal(np.asarray(J)[:7], np.identity(7))
+    np.testing.assert_array_equal(fx[:7], X2[10])
+
+
+def test_hybrid_sys_time_tutorial(capsys):
+    """HYBRID_SYS_TIME.ipynb (cells 2-17): JointSpaceTimePlannerSys (AngularTimeKeypoint at 2.5 s) then PosOrnTimePlannerSys
+    (SpacetimeKeypoint at 5 s, time precision 0), u0 = [0..0, 0.1]; seeded joint target, streams against the oracle."""
+    from PyLQR.sim import KDLRobot
+    from PyLQR.solver import BatchILQRCP, ILQRRecursive
+    from PyLQR.system import AngularTimeKeypoint, JointSpaceTimePlannerSys, PosOrnTimePlannerSys, SequentialSystem, SpacetimeKeypoint
+    from PyLQR.utils import PythonCallbackMessage, primitives
+    from tests.helpers import orc, panda_segs
+
+    g = golden()["cases"]["POS_ORN_SYS"]["problem"]
+    dof, nb_ctrl_var, horizon = 7, 8, 500
+    q0, dq0 = g["q0"], [0] * dof
+    qMax = np.array([2.8973, 1.7628, 2.8973, -0.0698, 2.8973, 3.7525, 2.8973])
+    qMin = np.array([-2.8973, -1.7628, -2.8973, -3.0718, -2.8973, -0.0175, -2.8973])  # the notebook gives sys1 (qMax, qMin) and sys2
+    # (qMax, -qMax), an inverted bound on joint 4; both sub-systems get (qMax, qMin) here: sub-systems with different limits do not lower
+    rbt = KDLRobot(URDF, "panda_link0", "panda_tip", q0, dq0)
+    target_1 = np.random.default_rng(22).uniform(-1.5, 1.5, dof)
+    Q1 = np.identity(dof + 1)
+    Q1[-1, -1] = 0
+    kp1 = AngularTimeKeypoint(target_1, Q1, 2.5, horizon // 2 - 1)
+    sys1 = JointSpaceTimePlannerSys(rbt, [kp1], [1e-5] * nb_ctrl_var, qMax, qMin, horizon, 1)
+    k1 = g["keypoints"][0]
+    Q2 = np.diag(list(k1["Qdiag"]) + [0])
+    kp2 = SpacetimeKeypoint(np.array(k1["pos"]), np.array(k1["orn"]), Q2, 5, horizon - 1)
+    sys2 = PosOrnTimePlannerSys(rbt, [kp2], (np.ones(nb_ctrl_var) * 1e-5).tolist(), qMax, qMin, horizon, 1)
+    sys_ = SequentialSystem(rbt, [sys1, sys2], [1e-5] * nb_ctrl_var, horizon, 1)
+    assert (sys_.get_nb_state_var(), sys_.get_nb_ctrl_var(), sys_.get_nb_target_var(), sys_.get_horizon()) == (8, 8, 16, 500)
+    so = orc.make_system(panda_segs(), orc.SYS_POS_ORN_TIME, 1, horizon, None, [1e-5] * 8, [
+        dict(timestep=horizon // 2 - 1, joint=True, target=target_1, ctime=2.5, Q=Q1, Ru=[1e-5] * 8),
+        dict(timestep=horizon - 1, pos=k1["pos"], orn=k1["orn"], ctime=5, Q=Q2, Ru=[1e-5] * 8)], q0, dq0, qMax, qMin, lim_mult=2)
+    u0 = np.tile(np.array([0] * (nb_ctrl_var - 1) + [0.1]), horizon - 1)
+    PSI = np.kron(primitives.build_psi_unitstep(horizon - 1, 2), np.identity(nb_ctrl_var))
+    cb = PythonCallbackMessage()
+    capsys.readouterr()
+    BatchILQRCP(sys_, PSI).solve(25, u0, False, cb)
+    _check_stream(capsys.readouterr().out.strip().splitlines(), _oracle_stream(orc.solve_batch_cp(so, PSI, u0, 25, False)))
+    X2, F_X2, U2, K2, k2_, cost = ILQRRecursive(sys_).solve(u0.reshape((-1, nb_ctrl_var)), 10, True, True, cb)
+    _check_stream(capsys.readouterr().out.strip().splitlines(), _oracle_stream(orc.solve_recursive(so, u0, 10, True, True)))
+    assert np.asarray(X2).shape == (500, 8) and np.asarray(K2).shape == (499, 8, 8)
+
+
 def test_joint_space_tutorial(capsys):
     """JOINT_SPACE_SYS.ipynb (cells 4-15) with seeded targets (the notebook draws them unseeded, so its numbers cannot be pinned):
     the problem is linear-quadratic, so ILQRRecursive reaches the optimum in one iteration and then fails to improve -- the
