@@ -36,17 +36,18 @@ def pmc_traffic(category):
     files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_kernels.txt")))
     if not files:
         return None, None
-    fetch = write = None
-    for line in open(files[-1]):
-        if ("k_" + category) not in line:
-            continue
-        if "FETCH_SIZE" in line:
-            fetch = float(line.split("avg=")[1].split()[0]) * 1024 * 2
-        elif "WRITE_SIZE" in line:
-            write = float(line.split("avg=")[1].split()[0]) * 1024
-    if fetch is None or write is None:
-        return None, None
-    return int(fetch + write), "profiles/" + os.path.basename(files[-1])
+    for f in reversed(files):  # newest summary that holds the counter passes for this kernel (summaries of other solvers have none)
+        fetch = write = None
+        for line in open(f):
+            if ("k_" + category) not in line:
+                continue
+            if "FETCH_SIZE" in line:
+                fetch = float(line.split("avg=")[1].split()[0]) * 1024 * 2
+            elif "WRITE_SIZE" in line:
+                write = float(line.split("avg=")[1].split()[0]) * 1024
+        if fetch is not None and write is not None:
+            return int(fetch + write), "profiles/" + os.path.basename(f)
+    return None, None
 
 
 def algorithmic_bytes(nx, nu, m, T, B):

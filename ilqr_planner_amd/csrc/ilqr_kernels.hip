@@ -81,7 +81,10 @@ __global__ __launch_bounds__(64) void k_backward(Bufs a) {
     UNR for (int i = 0; i < NX; i++) x[i] = AT(X, (T - 1) * NX + i, b);
     {
         const bool iskp = (kpi >= 0 && d.kp_t[kpi] == T - 1);
-        stage_derivs<S>(d, a, b, x, iskp ? kpi : -1, P, p);
+        // the keypoint code (FK, log map, frames, J'QJ) is called out of line: inlined twice into this kernel it drove the register
+        // allocator into spilling SGPRs to VGPR lanes
+        if (iskp) stage_derivs_call<S>(&d, &a, b, kpi, x, &P[0][0], p);
+        else stage_derivs<S>(d, a, b, x, -1, P, p);
         if (iskp) kpi--;
     }
     for (int k = T - 2; k >= 0; k--) {
@@ -107,7 +110,8 @@ __global__ __launch_bounds__(64) void k_backward(Bufs a) {
         double lxx[NX][NX], lx[NX];
         {
             const bool iskp = (kpi >= 0 && d.kp_t[kpi] == k);
-            stage_derivs<S>(d, a, b, x, iskp ? kpi : -1, lxx, lx);
+            if (iskp) stage_derivs_call<S>(&d, &a, b, kpi, x, &lxx[0][0], lx);
+            else stage_derivs<S>(d, a, b, x, -1, lxx, lx);
             if (iskp) kpi--;
         }
         // BtP = B^T P (NU x NX), AtP = A^T P (NX x NX)
