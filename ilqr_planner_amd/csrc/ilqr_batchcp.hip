@@ -22,16 +22,24 @@ namespace ilqr {
 
 #define PSI(k, q) c.psi[(size_t)(k) * KWP + (q)]
 
+// Lanes (instances) per workgroup of the one-lane-per-instance kernels.  These kernels are latency-bound chains (rollout, FK,
+// LU); at B = 8192 full waves would give 128 workgroups for 256 CUs.  Quarter waves spread the same lanes over four times as
+// many SIMDs, which run them at the same speed (a wave costs the same with 16 or 64 active lanes).
+#ifndef CP_LPB
+#define CP_LPB 16
+#endif
+constexpr int LPB = CP_LPB;
+
 template <class S, int KWP>
-__global__ __launch_bounds__(64) void k_cp_linearize(Bufs a, CPArgs c) {
+__global__ __launch_bounds__(LPB) void k_cp_linearize(Bufs a, CPArgs c) {
     constexpr int NX = S::NX, NU = S::NU;
     extern __shared__ double lds[];
     const DevDesc& d = *a.desc;
-    const int lane = threadIdx.x, b = blockIdx.x * 64 + lane;
+    const int lane = threadIdx.x, b = blockIdx.x * LPB + lane;
     if (b >= d.B || !a.active[b]) return;
     const int Bp = d.Bp, T = d.T;
-#define WL(r, q) lds[((r) * KWP + (q)) * 64 + lane]
-    for (int i = 0; i < NX * KWP; i++) lds[i * 64 + lane] = 0;
+#define WL(r, q) lds[((r) * KWP + (q)) * LPB + lane]
+    for (int i = 0; i < NX * KWP; i++) lds[i * LPB + lane] = 0;
     double x[NX], xp[NX], u[NU], gu[KWP];
     UNR for (int q = 0; q < KWP; q++) gu[q] = 0;
     init_state<S>(d, a, b, x);
@@ -56,7 +64,7 @@ __global__ __launch_bounds__(64) void k_cp_linearize(Bufs a, CPArgs c) {
             UNR for (int s = 0; s < NX; s++) AT(Ck, r * NX + s, b) = lxx[r][s] + ((r == s) ? Ld[r] : 0.0);
             AT(rk, r, b) = -lx[r] + Ld[r] * ql[r];
         }
-        for (int e = 0; e < NX * KWP; e++) AT(Wk, e, b) = lds[e * 64 + lane];
+        for (int e = 0; e < NX * KWP; e++) AT(Wk, e, b) = lds[e * LPB + lane];
         kpi++;
     };
 
@@ -95,14 +103,14 @@ __global__ __launch_bounds__(64) void k_cp_linearize(Bufs a, CPArgs c) {
 }
 
 template <class S, int KWP>
-__global__ __launch_bounds__(64) void k_cp_solve(Bufs a, CPArgs c) {
+__global__ __launch_bounds__(LPB) void k_cp_solve(Bufs a, CPArgs c) {
     constexpr int NX = S::NX;
     extern __shared__ double lds[];
     const DevDesc& d = *a.desc;
-    const int lane = threadIdx.x, b = blockIdx.x * 64 + lane;
+    const int lane = threadIdx.x, b = blockIdx.x * LPB + lane;
     if (b >= d.B || !a.active[b]) return;
     const int Bp = d.Bp;
-#define HL(r, q) lds[((r) * KWP + (q)) * 64 + lane]
+#define HL(r, q) lds[((r) * KWP + (q)) * LPB + lane]
     double g[KWP];
     UNR for (int q = 0; q < KWP; q++) g[q] = -AT(c.gu, q, b);
     for (int r = 0; r < KWP; r++)
@@ -168,11 +176,86 @@ __global__ __launch_bounds__(64) void k_cp_solve(Bufs a, CPArgs c) {
 #undef HL
 }
 
+// The same solve with one wave per instance: the Kw x Kw system sits in LDS once (not once per lane), lanes share the products
+// (entries of C W, of W'(C W)) and own a column each during the elimination.  Every entry sees the same operations in the same
+// order as in k_cp_solve (sums over i, j ascending; first-maximum pivot; the right-hand side eliminated along as an extra column
+// = the forward substitution with the stored multipliers), so the two kernels agree bit for bit.
 template <class S, int KWP>
-__global__ __launch_bounds__(64) void k_cp_linesearch(Bufs a, CPArgs c) {
+__global__ __launch_bounds__(64) void k_cp_solve_w(Bufs a, CPArgs c) {
+    constexpr int NX = S::NX;
+    __shared__ double Hs[KWP][KWP + 2], Ws[NX][KWP], Cs[NX][NX], CWs[NX][KWP], rs[NX], xs[KWP];
+    __shared__ int prS;
+    const DevDesc& d = *a.desc;
+    const int lane = threadIdx.x, b = blockIdx.x;
+    if (!a.active[b]) return;  // uniform: one instance per workgroup
+    const int Bp = d.Bp;
+    for (int e = lane; e < KWP * KWP; e += 64) Hs[e / KWP][e % KWP] = c.H0[e];
+    if (lane < KWP) Hs[lane][KWP] = -AT(c.gu, lane, b);
+    for (int t = 0; t < d.n_kp; t++) {
+        const double* Ck = c.Ckp + (size_t)t * NX * NX * Bp;
+        const double* rk = c.rkp + (size_t)t * NX * Bp;
+        __syncthreads();
+        for (int e = lane; e < NX * KWP; e += 64)
+            Ws[e / KWP][e % KWP] = c.wref ? c.wref[(size_t)t * NX * KWP + e] : AT(c.Wkp + (size_t)t * NX * KWP * Bp, e, b);
+        for (int e = lane; e < NX * NX; e += 64) Cs[e / NX][e % NX] = AT(Ck, e, b);
+        if (lane < NX) rs[lane] = AT(rk, lane, b);
+        __syncthreads();
+        for (int e = lane; e < NX * KWP; e += 64) {
+            const int i = e / KWP, q = e % KWP;
+            double s = 0;
+            UNR for (int j = 0; j < NX; j++) s += Cs[i][j] * Ws[j][q];
+            CWs[i][q] = s;
+        }
+        __syncthreads();
+        for (int e = lane; e < KWP * KWP; e += 64) {
+            const int r = e / KWP, q = e % KWP;
+            double s = 0;
+            UNR for (int i = 0; i < NX; i++) s += Ws[i][r] * CWs[i][q];
+            Hs[r][q] += s;
+        }
+        if (lane < KWP) {
+            double s = 0;
+            UNR for (int i = 0; i < NX; i++) s += Ws[i][lane] * rs[i];
+            Hs[lane][KWP] += s;
+        }
+    }
+    __syncthreads();
+    for (int k = 0; k < KWP; k++) {  // partial-pivot LU (Eigen PartialPivLU), lane q owns column q; column KWP = right-hand side
+        if (lane == 0) {
+            int pr = k;
+            double best = fabs(Hs[k][k]);
+            for (int i = k + 1; i < KWP; i++) {
+                const double v = fabs(Hs[i][k]);
+                if (v > best) { best = v; pr = i; }
+            }
+            prS = pr;
+        }
+        __syncthreads();
+        const int pr = prS;
+        if (lane <= KWP && lane >= k && pr != k) { const double t0 = Hs[k][lane]; Hs[k][lane] = Hs[pr][lane]; Hs[pr][lane] = t0; }
+        __syncthreads();
+        if (lane <= KWP && lane > k) {
+            const double pv = Hs[k][k], hk = Hs[k][lane];
+            for (int i = k + 1; i < KWP; i++) Hs[i][lane] -= (Hs[i][k] / pv) * hk;
+        }
+        __syncthreads();
+    }
+    if (lane == 0) {
+        for (int i = KWP - 1; i >= 0; i--) {
+            double s = Hs[i][KWP];
+            for (int j = i + 1; j < KWP; j++) s -= Hs[i][j] * xs[j];
+            xs[i] = s / Hs[i][i];
+        }
+    }
+    __syncthreads();
+    if (lane < KWP) AT(c.dw, lane, b) = xs[lane];
+}
+
+template <class S, int KWP>
+__global__ __launch_bounds__(LPB) void k_cp_linesearch(Bufs a, CPArgs c) {
     constexpr int NX = S::NX, NU = S::NU;
     const DevDesc& d = *a.desc;
-    const int b = blockIdx.x * 64 + threadIdx.x;
+    const int b = blockIdx.x * LPB + threadIdx.x;
     if (b >= d.B || !a.active[b]) return;
     const int Bp = d.Bp, T = d.T;
     double dw[KWP];
@@ -252,19 +335,30 @@ __global__ void k_cp_init(Bufs a) {
 
 // final rollout of the solution so that X (and the cost of the returned u) can be read back
 template <class S>
-__global__ __launch_bounds__(64) void k_cp_final(Bufs a) {
+__global__ __launch_bounds__(LPB) void k_cp_final(Bufs a) {
     constexpr int NX = S::NX, NU = S::NU;
     const DevDesc& d = *a.desc;
-    const int b = blockIdx.x * 64 + threadIdx.x;
+    const int b = blockIdx.x * LPB + threadIdx.x;
     if (b >= d.B) return;
     const int Bp = d.Bp, T = d.T;
     double x[NX], u[NU], xn[NX];
     init_state<S>(d, a, b, x);
-    for (int s = 0; s < T - 1; s++) {
-        UNR for (int i = 0; i < NX; i++) AT(a.X[0], s * NX + i, b) = x[i];
-        UNR for (int i = 0; i < NU; i++) u[i] = AT(a.U[0], s * NU + i, b);
-        dyn_step<S>(d, x, u, xn);
-        UNR for (int i = 0; i < NX; i++) x[i] = xn[i];
+    constexpr int G = 8;  // the controls of G steps are fetched together: one memory latency per group instead of one per step
+    for (int s0 = 0; s0 < T - 1; s0 += G) {
+        double ug[G][NU];
+        UNR for (int k = 0; k < G; k++) {
+            const int s = (s0 + k < T - 1) ? s0 + k : T - 2;
+            UNR for (int i = 0; i < NU; i++) ug[k][i] = AT(a.U[0], s * NU + i, b);
+        }
+        UNR for (int k = 0; k < G; k++) { UNR for (int i = 0; i < NU; i++) asm volatile("" : "+v"(ug[k][i])); }
+        UNR for (int k = 0; k < G; k++) {
+            const int s = s0 + k;
+            if (s >= T - 1) break;
+            UNR for (int i = 0; i < NX; i++) AT(a.X[0], s * NX + i, b) = x[i];
+            UNR for (int i = 0; i < NU; i++) u[i] = ug[k][i];
+            dyn_step<S>(d, x, u, xn);
+            UNR for (int i = 0; i < NX; i++) x[i] = xn[i];
+        }
     }
     UNR for (int i = 0; i < NX; i++) AT(a.X[0], (T - 1) * NX + i, b) = x[i];
 }
@@ -318,37 +412,45 @@ ILQR_DEV double cpl_cost(const DevDesc& d, const Bufs& a, const CPArgs& c, int b
     return cost_e + ((c00 + 2 * lin) + quad) + cost_l;
 }
 
+// KWP lanes per instance: lane q accumulates PSI'R u0 for its own column q (the long part of this pass: (T-1) n_u terms per column,
+// basis rows read as coalesced vector loads; with one lane per instance they are uniform -> scalar loads whose latency, one per
+// control entry, bounds the kernel).  All lanes walk the rollout of u0, lane 0 records the states at the keypoint steps.
 template <class S, int KWP>
 __global__ __launch_bounds__(64) void k_cpl_init(Bufs a, CPArgs c) {
-    constexpr int NX = S::NX, NU = S::NU;
+    constexpr int NX = S::NX, NU = S::NU, IPB = 64 / KWP;
+    static_assert(64 % KWP == 0, "KWP lanes per instance");
     const DevDesc& d = *a.desc;
-    const int b = blockIdx.x * 64 + threadIdx.x;
+    const int q = threadIdx.x % KWP, b = blockIdx.x * IPB + threadIdx.x / KWP;
     if (b >= d.B) return;
     const int Bp = d.Bp, T = d.T;
-    double x[NX], xp[NX], u[NU], xn[NX], g0[KWP];
-    UNR for (int q = 0; q < KWP; q++) g0[q] = 0;
+    double x[NX], xp[NX], u[NU], xn[NX], g0 = 0;
     init_state<S>(d, a, b, x);
     UNR for (int i = 0; i < NX; i++) xp[i] = x[i];
     double c00 = 0;
     int kpi = 0;
     auto record = [&]() {
-        double* xb = c.xbk + (size_t)kpi * 2 * NX * Bp;
-        UNR for (int r = 0; r < NX; r++) { AT(xb, r, b) = x[r]; AT(xb, NX + r, b) = xp[r]; }
+        if (q == 0) {
+            double* xb = c.xbk + (size_t)kpi * 2 * NX * Bp;
+            UNR for (int r = 0; r < NX; r++) { AT(xb, r, b) = x[r]; AT(xb, NX + r, b) = xp[r]; }
+        }
         kpi++;
     };
     if (kpi < d.n_kp && d.kp_t[kpi] == 0) record();
+#pragma unroll 4
     for (int s = 0; s < T - 1; s++) {
         UNR for (int i = 0; i < NU; i++) {
             u[i] = AT(a.U0, s * NU + i, b);
             const double ru = d.R_diag[i] * u[i];
             c00 += u[i] * ru;
-            UNR for (int q = 0; q < KWP; q++) g0[q] += PSI(s * NU + i, q) * ru;
+            g0 += PSI(s * NU + i, q) * ru;
         }
         dyn_step<S>(d, x, u, xn);
         UNR for (int i = 0; i < NX; i++) { xp[i] = x[i]; x[i] = xn[i]; }
         if (kpi < d.n_kp && d.kp_t[kpi] == s + 1) record();
     }
-    UNR for (int q = 0; q < KWP; q++) { AT(c.g0, q, b) = g0[q]; AT(c.wv, q, b) = 0; }
+    AT(c.g0, q, b) = g0;
+    AT(c.wv, q, b) = 0;
+    if (q != 0) return;
     c.c00[b] = c00;
     a.cur[b] = 0;
     a.active[b] = 1;
@@ -366,16 +468,19 @@ __global__ void k_cpl_bcast(const double* __restrict__ wref, double* __restrict_
     if (b < B && e < n_entries) Wkp[(size_t)e * Bp + b] = wref[e];
 }
 
+// One lane per (instance, keypoint): the two keypoint linearisations of an instance (FK, Jacobian, J'QJ) run side by side.  The lane
+// of keypoint 0 also forms PSI'R u and, in the first iteration, cost0; later cost0 is the cost of the trial the line search
+// accepted -- the same function of the same w, already in a.cost.
 template <class S, int KWP>
-__global__ __launch_bounds__(64) void k_cpl_linearize(Bufs a, CPArgs c) {
+__global__ __launch_bounds__(LPB) void k_cpl_linearize(Bufs a, CPArgs c) {
     constexpr int NX = S::NX;
     const DevDesc& d = *a.desc;
-    const int b = blockIdx.x * 64 + threadIdx.x;
+    const int b = blockIdx.x * LPB + threadIdx.x, kpi = blockIdx.y;
     if (b >= d.B || !a.active[b]) return;
     const int Bp = d.Bp;
-    double w[KWP], g0[KWP];
-    UNR for (int q = 0; q < KWP; q++) { w[q] = AT(c.wv, q, b); g0[q] = AT(c.g0, q, b); }
-    for (int kpi = 0; kpi < d.n_kp; kpi++) {
+    double w[KWP];
+    UNR for (int q = 0; q < KWP; q++) w[q] = AT(c.wv, q, b);
+    if (kpi < d.n_kp) {
         double x[NX], xp[NX], lxx[NX][NX], lx[NX], Ld[NX], ql[NX];
         cpl_states<S, KWP>(d, c, b, kpi, w, x, xp);
         stage_derivs<S, false>(d, a, b, x, kpi, lxx, lx);  // lxx = J'QJ, lx = -J'Q e
@@ -388,7 +493,10 @@ __global__ __launch_bounds__(64) void k_cpl_linearize(Bufs a, CPArgs c) {
             AT(rk, r, b) = -lx[r] + Ld[r] * ql[r];
         }
     }
-    a.cost[b] = cpl_cost<S, KWP>(d, a, c, b, w, g0, c.c00[b]);  // cost0 of this iteration (BatchILQRCP.cpp:135)
+    if (kpi != 0) return;
+    double g0[KWP];
+    UNR for (int q = 0; q < KWP; q++) g0[q] = AT(c.g0, q, b);
+    if (c.it == 0) a.cost[b] = cpl_cost<S, KWP>(d, a, c, b, w, g0, c.c00[b]);  // cost0 (BatchILQRCP.cpp:135)
     UNR for (int q = 0; q < KWP; q++) {  // PSI'R u = PSI'R u0 + (PSI'R PSI) w   (padded rows of H0: identity x 0)
         double s = g0[q];
         UNR for (int r = 0; r < KWP; r++) s += ((q < c.Kw && r < c.Kw) ? c.H0[q * KWP + r] : 0.0) * w[r];
@@ -396,11 +504,15 @@ __global__ __launch_bounds__(64) void k_cpl_linearize(Bufs a, CPArgs c) {
     }
 }
 
+// Backtracking with all step sizes at once: 16 lanes per instance, lane l tries alpha = 2^-l (l = 0 .. 10; the reference's loop
+// stops at the first alpha whose cost improves or at alpha < 1e-3, BatchILQRCP.cpp:138-158 -- the first such lane wins).  The chain a
+// lane walks is one cost evaluation instead of up to eleven.
 template <class S, int KWP>
 __global__ __launch_bounds__(64) void k_cpl_linesearch(Bufs a, CPArgs c) {
     const DevDesc& d = *a.desc;
-    const int b = blockIdx.x * 64 + threadIdx.x;
-    if (b >= d.B || !a.active[b]) return;
+    const int lane = threadIdx.x, l = lane & 15, bq = blockIdx.x * 4 + (lane >> 4);
+    const bool ok = bq < d.B && a.active[bq < d.B ? bq : 0];
+    const int b = ok ? bq : 0;
     const int Bp = d.Bp;
     double w[KWP], dw[KWP], g0[KWP], wn[KWP];
     UNR for (int q = 0; q < KWP; q++) { w[q] = AT(c.wv, q, b); dw[q] = AT(c.dw, q, b); g0[q] = AT(c.g0, q, b); }
@@ -411,13 +523,14 @@ __global__ __launch_bounds__(64) void k_cpl_linesearch(Bufs a, CPArgs c) {
         dun2 += dw[q] * s;
     }
     const double cost0 = a.cost[b], c00 = c.c00[b];
-    double alpha = 1.0, cost = 0;
-    while (true) {  // BatchILQRCP.cpp:138-158
-        UNR for (int q = 0; q < KWP; q++) wn[q] = w[q] + alpha * dw[q];
-        cost = cpl_cost<S, KWP>(d, a, c, b, wn, g0, c00);
-        if ((cost < cost0) || (alpha < 1e-3)) break;
-        alpha /= 2;
-    }
+    const double alpha = ldexp(1.0, -(l < 11 ? l : 10));
+    UNR for (int q = 0; q < KWP; q++) wn[q] = w[q] + alpha * dw[q];
+    const double cost = cpl_cost<S, KWP>(d, a, c, b, wn, g0, c00);
+    const bool take = (l < 11) && ((cost < cost0) || (alpha < 1e-3));
+    const unsigned long long m = __ballot(take ? 1 : 0);
+    const unsigned grp = (unsigned)((m >> (lane & 48)) & 0xffffull);  // this instance's 16 lanes; lane 10 always votes
+    const int win = __ffs(grp) - 1;
+    if (!ok || l != win) return;
     UNR for (int q = 0; q < KWP; q++) AT(c.wv, q, b) = wn[q];
     a.alpha[b] = alpha;
     a.iters[b] = c.it + 1;
@@ -468,8 +581,8 @@ template <class S, int KWP>
 static int run_cp(BatchCPState& st, const DevDesc& h, Bufs& bufs, int nb_iter, int early_stop, hipStream_t stream, std::string& err) {
     constexpr int NX = S::NX;
     const int B = h.B;
-    const dim3 grid((B + 63) / 64), block(64);
-    const size_t lds_w = sizeof(double) * NX * KWP * 64, lds_h = sizeof(double) * KWP * KWP * 64;
+    const dim3 grid((B + LPB - 1) / LPB), block(LPB);
+    const size_t lds_w = sizeof(double) * NX * KWP * LPB, lds_h = sizeof(double) * KWP * KWP * LPB;
     if (lds_w > 160 * 1024 || lds_h > 160 * 1024) { err = "ilqr_solve_batch_cp: basis too wide for the LDS tiles (n_x * Kw <= 320, Kw <= 16)"; return 1; }
     if (hipFuncSetAttribute((const void*)k_cp_linearize<S, KWP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_cp_solve<S, KWP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h) != hipSuccess) {
@@ -479,11 +592,14 @@ static int run_cp(BatchCPState& st, const DevDesc& h, Bufs& bufs, int nb_iter, i
     CPArgs c;
     c.psi = st.psi; c.H0 = st.H0; c.Wkp = st.Wkp; c.Ckp = st.Ckp; c.rkp = st.rkp; c.gu = st.gu; c.dw = st.dw; c.dun = st.dun;
     c.Kw = st.Kw; c.early_stop = early_stop; c.n_alpha = 11; c.it = 0;
+    c.wref = nullptr;
+    const bool wave_solve = !(std::getenv("ILQR_CP_SOLVE") && !std::strcmp(std::getenv("ILQR_CP_SOLVE"), "lane"));  // cross-check: lane per instance
     hipLaunchKernelGGL((k_cp_init<S>), dim3((B + 255) / 256), dim3(256), 0, stream, bufs);
     for (int it = 0; it < nb_iter; it++) {
         c.it = it;
         hipLaunchKernelGGL((k_cp_linearize<S, KWP>), grid, block, lds_w, stream, bufs, c);
-        hipLaunchKernelGGL((k_cp_solve<S, KWP>), grid, block, lds_h, stream, bufs, c);
+        if (wave_solve) hipLaunchKernelGGL((k_cp_solve_w<S, KWP>), dim3(B), dim3(64), 0, stream, bufs, c);
+        else hipLaunchKernelGGL((k_cp_solve<S, KWP>), grid, block, lds_h, stream, bufs, c);
         hipLaunchKernelGGL((k_cp_linesearch<S, KWP>), grid, block, 0, stream, bufs, c);
     }
     hipLaunchKernelGGL((k_cp_final<S>), grid, block, 0, stream, bufs);
@@ -534,8 +650,8 @@ static int run_cpl(BatchCPState& st, const DevDesc& h, Bufs& bufs, const std::ve
         err = "ilqr_solve_batch_cp: sensitivity upload failed";
         return 1;
     }
-    const dim3 grid((B + 63) / 64), block(64);
-    const size_t lds_h = sizeof(double) * KWP * KWP * 64;
+    const dim3 grid((B + LPB - 1) / LPB), block(LPB);
+    const size_t lds_h = sizeof(double) * KWP * KWP * LPB;
     if (hipFuncSetAttribute((const void*)k_cp_solve<S, KWP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h) != hipSuccess) {
         err = "ilqr_solve_batch_cp: cannot reserve LDS";
         return 1;
@@ -544,15 +660,18 @@ static int run_cpl(BatchCPState& st, const DevDesc& h, Bufs& bufs, const std::ve
     c.psi = st.psi; c.H0 = st.H0; c.Wkp = st.Wkp; c.Ckp = st.Ckp; c.rkp = st.rkp; c.gu = st.gu; c.dw = st.dw; c.dun = st.dun;
     c.wt = st.wt; c.pp = st.pp; c.wv = st.wv; c.g0 = st.g0; c.c00 = st.c00; c.xbk = st.xbk;
     c.Kw = st.Kw; c.early_stop = early_stop; c.n_alpha = 11; c.it = 0;
-    hipLaunchKernelGGL((k_cpl_init<S, KWP>), grid, block, 0, stream, bufs, c);
+    c.wref = st.wref;
+    const bool wave_solve = !(std::getenv("ILQR_CP_SOLVE") && !std::strcmp(std::getenv("ILQR_CP_SOLVE"), "lane"));  // cross-check: lane per instance
+    hipLaunchKernelGGL((k_cpl_init<S, KWP>), dim3((B + 64 / KWP - 1) / (64 / KWP)), dim3(64), 0, stream, bufs, c);
     if (nkp > 0) hipLaunchKernelGGL(k_cpl_bcast, dim3((B + 255) / 256, nkp * NX * KWP), dim3(256), 0, stream, st.wref, st.Wkp, nkp * NX * KWP, B, h.Bp);
     for (int it = 0; it < nb_iter; it++) {
         c.it = it;
-        hipLaunchKernelGGL((k_cpl_linearize<S, KWP>), grid, block, 0, stream, bufs, c);
-        hipLaunchKernelGGL((k_cp_solve<S, KWP>), grid, block, lds_h, stream, bufs, c);
-        hipLaunchKernelGGL((k_cpl_linesearch<S, KWP>), grid, block, 0, stream, bufs, c);
+        hipLaunchKernelGGL((k_cpl_linearize<S, KWP>), dim3((B + LPB - 1) / LPB, nkp > 0 ? nkp : 1), block, 0, stream, bufs, c);
+        if (wave_solve) hipLaunchKernelGGL((k_cp_solve_w<S, KWP>), dim3(B), dim3(64), 0, stream, bufs, c);
+        else hipLaunchKernelGGL((k_cp_solve<S, KWP>), grid, block, lds_h, stream, bufs, c);
+        hipLaunchKernelGGL((k_cpl_linesearch<S, KWP>), dim3((B + 3) / 4), dim3(64), 0, stream, bufs, c);
     }
-    hipLaunchKernelGGL((k_cpl_controls<S, KWP>), dim3((B + 63) / 64, T - 1), block, 0, stream, bufs, c);
+    hipLaunchKernelGGL((k_cpl_controls<S, KWP>), dim3((B + 63) / 64, T - 1), dim3(64), 0, stream, bufs, c);
     hipLaunchKernelGGL((k_cp_final<S>), grid, block, 0, stream, bufs);
     if (hipGetLastError() != hipSuccess) { err = "ilqr_solve_batch_cp: kernel launch failed"; return 1; }
     return 0;

@@ -37,6 +37,7 @@ struct CPArgs {
     const double* H0;
     double *Wkp, *Ckp, *rkp, *gu, *dw, *dun;
     const double *wt, *pp;
+    const double* wref;  // shared W = Su PSI at the keypoint steps (constant-dt systems) or null: per-instance Wkp
     double *wv, *g0, *c00, *xbk;
     int Kw, it, early_stop, n_alpha;
 };

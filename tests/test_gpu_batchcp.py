@@ -66,6 +66,27 @@ def test_cp_random_batch_vs_oracle(ctx, cfg_name, B, nb_iter):
     p.close()
 
 
+@pytest.mark.parametrize("cfg_name,B,nb_iter", [("C5", 70, 5), ("C4cp", 20, 4)])
+def test_wave_solve_equals_lane_solve(ctx, cfg_name, B, nb_iter, monkeypatch):
+    """The Kw x Kw normal equations solved by one wave per instance (default) and by one lane per instance (ILQR_CP_SOLVE=lane) run
+    the same operations on every entry in the same order: identical results, bit for bit."""
+    from ilqr_planner_amd import workloads
+
+    cfg = workloads.config(cfg_name)
+    cfg["T"] = min(cfg["T"], 60)
+    desc, inp = workloads.make_batch(ctx, cfg, B=B, limits="urdf")
+    psi = psi_of(cfg["psi"], cfg["T"], 7 + (1 if cfg["kind"] == 1 else 0))
+    out = []
+    for mode in ("wave", "lane"):
+        monkeypatch.setenv("ILQR_CP_SOLVE", mode)
+        p = workloads.load_batch(ctx, desc, inp, B)
+        p.solve_batch_cp(psi, nb_iter, False)
+        out.append((p.U(), p.trace(nb_iter)[0]))
+        p.close()
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+
+
 def test_cp_on_a_sequence_ignores_limits(ctx):
     """Batch-CP on a (hybrid) SequentialSystem: joint-space via point + pose goal, and NO limit terms although the sub-systems have
     violated limits -- SequentialSystem does not override fpBatch, which runs on the sequence object built without limits
