@@ -50,11 +50,11 @@ struct BatchWideState {
     // LTI systems: shared tables
     double *G = nullptr, *Et = nullptr, *ZPZ = nullptr, *PZ = nullptr;
     // per instance
-    double *xbk = nullptr, *av = nullptr, *v0 = nullptr, *p0 = nullptr, *scal = nullptr, *cv = nullptr, *beta = nullptr,
+    double *xbk = nullptr, *av = nullptr, *v0 = nullptr, *p0 = nullptr, *scal = nullptr, *cv = nullptr, *beta = nullptr, *dvb = nullptr, *sc = nullptr,
            *Ckp = nullptr, *rkp = nullptr, *u0hat = nullptr, *g0 = nullptr, *y0 = nullptr, *psi = nullptr, *h0inv = nullptr;
 };
 int batchwide_solve(BatchWideState& st, const DevDesc& h, Bufs& bufs, int nx, int nu, const double* psi_host, int Kw, int nb_iter, int early_stop,
-                    hipStream_t stream, std::string& err);
+                    bool u0_zero, hipStream_t stream, std::string& err);
 void batchwide_free(BatchWideState& st);
 
 int batchcp_solve(BatchCPState& st, const DevDesc& h, Bufs& bufs, int nx, int nu, int nf, int nq, const double* psi_host, int Kw,

@@ -14,7 +14,7 @@
 // because the Gauss-Newton step is dw = Z d - beta y0 with d = (I + C G)^-1 (r - c + beta C V y0), r = stacked J'Qe + L ql:
 //     beta <- (1 - alpha) beta,   c <- c + alpha d.
 // States at the keypoint steps are affine in (beta, c), the control cost is a quadratic form in them, ||PSI dw|| likewise: an
-// iteration touches m + 1 numbers per instance and never walks the horizon (k_wl_iter).  The horizon is walked twice per solve:
+// iteration touches m + 1 numbers per instance and never walks the horizon (k_wl_linearize, k_wl_solve, k_wl_linesearch).  The horizon is walked twice per solve:
 // k_wl_init (rollouts of u0, of its projection u0^ = PSI y0 and of u = 0) and k_wl_controls + k_wide_final (u, X out).
 //
 // Time systems (dt = u_last^2: A, B depend on the iterate) -- identity basis only (BatchILQR).  V is per instance and iterate but
@@ -36,7 +36,7 @@ namespace ilqr {
 
 struct WArgs {
     const double *G, *Et, *ZPZ, *PZ;  // shared tables (LTI)
-    double *xbk, *av, *v0, *p0, *scal, *cv, *beta, *Ckp, *rkp;
+    double *xbk, *av, *v0, *p0, *scal, *cv, *beta, *Ckp, *rkp, *dvb, *sc;
     const double* u0hat;
     int m, it, early_stop;
 };
@@ -76,33 +76,38 @@ __device__ __noinline__ void w_kp_derivs(const DevDesc* d, const Bufs* a, int b,
 
 // ------------------------------------------------------------------------------------------------ LTI systems
 
+// MC lanes per instance: lane j accumulates p0[j] = (PSI Z)[:, j] . u0^ from coalesced rows of PZ (with one lane per instance
+// the rows are uniform -> scalar loads, one latency per control entry); all lanes walk the three rollouts, lane 0 records.
 template <class S, int MC>
 __global__ __launch_bounds__(64) void k_wl_init(Bufs a, WArgs c) {
-    constexpr int NX = S::NX, NU = S::NU;
+    constexpr int NX = S::NX, NU = S::NU, IPB = 64 / MC;
     const DevDesc& d = *a.desc;
-    const int b = blockIdx.x * 64 + threadIdx.x;
+    const int j = threadIdx.x % MC, b = blockIdx.x * IPB + threadIdx.x / MC;
     if (b >= d.B) return;
     const int Bp = d.Bp, T = d.T, m = c.m;
-    double x[NX], xp[NX], xh[NX], xhp[NX], xz[NX], xzp[NX], sv[NX], u[NU], uh[NU], zero[NU], xn[NX], p0[MC];
-    UNR for (int j = 0; j < MC; j++) p0[j] = 0;
+    const int jj = j < m ? j : 0;
+    double x[NX], xp[NX], xh[NX], xhp[NX], xz[NX], xzp[NX], sv[NX], u[NU], uh[NU], zero[NU], xn[NX], p0 = 0;
     UNR for (int i = 0; i < NU; i++) zero[i] = 0;
     init_state<S>(d, a, b, x);
     UNR for (int i = 0; i < NX; i++) { xp[i] = xh[i] = xhp[i] = xz[i] = xzp[i] = x[i]; sv[i] = 0; }
     double c00 = 0, gam = 0, pi = 0;
     int kpi = 0;
     auto record = [&]() {
-        double* xb = c.xbk + (size_t)kpi * 2 * NX * Bp;
-        double* ab = c.av + (size_t)kpi * 2 * NX * Bp;
-        UNR for (int r = 0; r < NX; r++) {
-            AT(xb, r, b) = x[r];
-            AT(xb, NX + r, b) = xp[r];
-            AT(ab, r, b) = xh[r] - xz[r];         // Wt_t y0: response of the trajectory to the projected u0
-            AT(ab, NX + r, b) = xhp[r] - xzp[r];  // Wt_{t-1} y0
-            AT(c.v0, kpi * NX + r, b) = sv[r];    // V y0 (shifted sensitivity)
+        if (j == 0) {
+            double* xb = c.xbk + (size_t)kpi * 2 * NX * Bp;
+            double* ab = c.av + (size_t)kpi * 2 * NX * Bp;
+            UNR for (int r = 0; r < NX; r++) {
+                AT(xb, r, b) = x[r];
+                AT(xb, NX + r, b) = xp[r];
+                AT(ab, r, b) = xh[r] - xz[r];         // Wt_t y0: response of the trajectory to the projected u0
+                AT(ab, NX + r, b) = xhp[r] - xzp[r];  // Wt_{t-1} y0
+                AT(c.v0, kpi * NX + r, b) = sv[r];    // V y0 (shifted sensitivity)
+            }
         }
         kpi++;
     };
     if (kpi < d.n_kp && d.kp_t[kpi] == 0) record();
+#pragma unroll 2
     for (int s = 0; s < T - 1; s++) {
         UNR for (int i = 0; i < NU; i++) {
             u[i] = AT(a.U0, s * NU + i, b);
@@ -110,9 +115,7 @@ __global__ __launch_bounds__(64) void k_wl_init(Bufs a, WArgs c) {
             c00 += u[i] * d.R_diag[i] * u[i];
             gam += u[i] * d.R_diag[i] * uh[i];
             pi += uh[i] * uh[i];
-            const double* pz = c.PZ + (size_t)(s * NU + i) * m;
-            UNR for (int j = 0; j < MC; j++)
-                if (j < m) p0[j] += pz[j] * uh[i];
+            p0 += c.PZ[(size_t)(s * NU + i) * m + jj] * uh[i];
         }
         dyn_step<S>(d, x, u, xn);
         UNR for (int i = 0; i < NX; i++) { xp[i] = x[i]; x[i] = xn[i]; }
@@ -123,8 +126,8 @@ __global__ __launch_bounds__(64) void k_wl_init(Bufs a, WArgs c) {
         if (s >= 1) lin_step<S>(d, sv, uh);  // block 0 of the reference's Su is zero
         if (kpi < d.n_kp && d.kp_t[kpi] == s + 1) record();
     }
-    UNR for (int j = 0; j < MC; j++)
-        if (j < m) { AT(c.p0, j, b) = p0[j]; AT(c.cv, j, b) = 0; }
+    if (j < m) { AT(c.p0, j, b) = p0; AT(c.cv, j, b) = 0; }
+    if (j != 0) return;
     AT(c.scal, 0, b) = c00;
     AT(c.scal, 1, b) = gam;
     AT(c.scal, 2, b) = pi;
@@ -179,125 +182,151 @@ ILQR_DEV double wl_task_cost(const DevDesc& d, const Bufs& a, const WArgs& c, in
     return cost_e + cost_l;
 }
 
-// the m x (m+1) system [I + C G | rhs] of one instance lives in LDS, column `lane` of an [m (m+1)][LPB] tile
-#define MX(r, q) lds[((r) * (m + 1) + (q)) * LPB + lane]
-#define RH(r) MX(r, m)
-
-// M x = rhs by LU with partial pivoting, in place; x left in the rhs column
-template <int LPB>
-ILQR_DEV void wide_lu_solve(double* lds, int m, int lane) {
-    for (int k = 0; k < m; k++) {
-        int pr = k;
-        double pv = fabs(MX(k, k));
-        for (int i = k + 1; i < m; i++) {
-            const double v = fabs(MX(i, k));
-            if (v > pv) { pv = v; pr = i; }
-        }
-        if (pr != k) {
-            for (int q = k; q <= m; q++) { const double t0 = MX(k, q); MX(k, q) = MX(pr, q); MX(pr, q) = t0; }
-        }
-        const double piv = MX(k, k);
-        for (int i = k + 1; i < m; i++) {
-            const double f = MX(i, k) / piv;
-            for (int q = k + 1; q <= m; q++) MX(i, q) -= f * MX(k, q);
-        }
-    }
-    for (int i = m - 1; i >= 0; i--) {
-        double s = RH(i);
-        for (int q = i + 1; q < m; q++) s -= MX(i, q) * RH(q);
-        RH(i) = s / MX(i, i);
-    }
+// control cost of the family member (beta (1 - al), c + al d):  u'Ru = c00 + (bn^2 - 1) gamma + 2 bn v0.(c + al d) + (c + al d)'G(c + al d)
+ILQR_DEV double wl_uru(double c00, double gam, double bn, double al, double v0c, double v0d, double cGc, double cGd, double dGd) {
+    return c00 + (bn * bn - 1) * gam + 2 * bn * (v0c + al * v0d) + ((cGc + 2 * al * cGd) + al * al * dGd);
 }
 
-// LPB lanes (instances) per block: the LDS tile of the linear system bounds it (m = 14: 32 lanes x 1.7 KB; m = 28: 16 lanes x 6.5 KB),
-// and smaller blocks mean more of them: the kernel is latency-bound, not throughput-bound (B / LPB waves for 256 CUs)
-template <class S, int MC, int LPB>
-__global__ __launch_bounds__(LPB) void k_wl_iter(Bufs a, WArgs c) {
+// Linearisation at the current iterate, one lane per (instance, keypoint): C_k = J'QJ + L, r_k = J'Q e + L ql (System::fpBatch +
+// BatchILQRCP.cpp:129-133).  cost0 is formed in the first iteration only; afterwards it is the cost of the accepted trial (a.cost).
+template <class S, int MC>
+__global__ __launch_bounds__(16) void k_wl_linearize(Bufs a, WArgs c) {
     constexpr int NX = S::NX;
-    extern __shared__ double lds[];
     const DevDesc& d = *a.desc;
-    const int lane = threadIdx.x, b = blockIdx.x * LPB + lane;
+    const int b = blockIdx.x * 16 + threadIdx.x, kpi = blockIdx.y;
     if (b >= d.B || !a.active[b]) return;
     const int Bp = d.Bp, m = c.m;
     double cv[MC], dv[MC];
     UNR for (int j = 0; j < MC; j++) { cv[j] = (j < m) ? AT(c.cv, j, b) : 0.0; dv[j] = 0; }
-    const double beta = c.beta[b], c00 = AT(c.scal, 0, b), gam = AT(c.scal, 1, b), pi = AT(c.scal, 2, b);
-
-    // linearisation at the current iterate: C_k = J'QJ + L, r_k = J'Q e + L ql (System::fpBatch + BatchILQRCP.cpp:129-133)
-    double cost_e = 0, cost_l = 0;
-    for (int kpi = 0; kpi < d.n_kp; kpi++) {
+    const double beta = c.beta[b];
+    {
         double x[NX], xp[NX], lxx[NX * NX], lx[NX], Ld[NX], ql[NX];
         wl_states<S, MC>(d, c, b, kpi, beta, cv, dv, 0.0, x, xp);
         w_kp_derivs<S>(&d, &a, b, kpi, x, lxx, lx);
         if (d.kp_t[kpi] > 0) limit_terms<S>(d, xp, Ld, ql);
         else { UNR for (int r = 0; r < NX; r++) { Ld[r] = 0; ql[r] = 0; } }
-        cost_e += w_kp_cost<S>(&d, a.kp_tg, b, kpi, x);
-        UNR for (int r = 0; r < NX; r++) cost_l += ql[r] * Ld[r] * ql[r];
         double* Ck = c.Ckp + (size_t)kpi * NX * NX * Bp;
         UNR for (int r = 0; r < NX; r++) {
             UNR for (int s = 0; s < NX; s++) AT(Ck, r * NX + s, b) = lxx[r * NX + s] + ((r == s) ? Ld[r] : 0.0);
             AT(c.rkp, kpi * NX + r, b) = -lx[r] + Ld[r] * ql[r];
         }
     }
-    // u'Ru = c00 + (beta^2 - 1) gamma + 2 beta v0.c + c'G c  and its change along (beta (1 - al), c + al d)
+    if (kpi != 0 || c.it != 0) return;
     double v0c = 0, cGc = 0;
     for (int i = 0; i < m; i++) {
         double s = 0;
         UNR for (int j = 0; j < MC; j++)
             if (j < m) s += c.G[(size_t)i * m + j] * cv[j];
-        const double ci = AT(c.cv, i, b);
-        cGc += ci * s;
-        v0c += AT(c.v0, i, b) * ci;
+        cGc += AT(c.cv, i, b) * s;
+        v0c += AT(c.v0, i, b) * AT(c.cv, i, b);
     }
-    const double cost0 = (cost_e + (c00 + (beta * beta - 1) * gam + 2 * beta * v0c + cGc)) + cost_l;
+    a.cost[b] = wl_task_cost<S, MC>(d, a, c, b, beta, cv, dv, 0.0) + wl_uru(AT(c.scal, 0, b), AT(c.scal, 1, b), beta, 0.0, v0c, 0.0, cGc, 0.0, 0.0);
+}
 
-    // (I + C G) d = (r - c) + beta C v0
-    for (int kpi = 0; kpi < d.n_kp; kpi++) {
+// (I + C G) d = (r - c) + beta C v0 with one wave per instance: the m x (m+1) system in LDS, lane q owns column q during the
+// partial-pivot elimination (column m = right-hand side).  Leaves d and the scalars the line search needs:
+//   sc = { v0.c, c'Gc, v0.d, c'Gd, d'Gd, ||PSI dw||^2 },  dw = Z d - beta y0
+template <class S, int MC>
+__global__ __launch_bounds__(64) void k_wl_solve(Bufs a, WArgs c) {
+    constexpr int NX = S::NX;
+    __shared__ double Ms[MC][MC + 2], xs[MC], cs[MC], t1[MC], t2[MC], t3[MC];
+    __shared__ int prS;
+    const DevDesc& d = *a.desc;
+    const int lane = threadIdx.x, b = blockIdx.x;
+    if (!a.active[b]) return;  // uniform
+    const int Bp = d.Bp, m = c.m;
+    const double beta = c.beta[b];
+    for (int e = lane; e < m * (m + 1); e += 64) {
+        const int row = e / (m + 1), col = e % (m + 1), kpi = row / NX, i = row % NX;
         const double* Ck = c.Ckp + (size_t)kpi * NX * NX * Bp;
-        double v0k[NX];
-        UNR for (int j = 0; j < NX; j++) v0k[j] = AT(c.v0, kpi * NX + j, b);
-        for (int i = 0; i < NX; i++) {
-            double ck[NX], cv0 = 0;
-            UNR for (int j = 0; j < NX; j++) { ck[j] = AT(Ck, i * NX + j, b); cv0 += ck[j] * v0k[j]; }
-            const int row = kpi * NX + i;
-            RH(row) = (AT(c.rkp, row, b) - AT(c.cv, row, b)) + beta * cv0;
-            for (int col = 0; col < m; col++) {
-                double s = (row == col) ? 1.0 : 0.0;
-                UNR for (int j = 0; j < NX; j++) s += ck[j] * c.G[(size_t)(kpi * NX + j) * m + col];
-                MX(row, col) = s;
+        double s;
+        if (col == m) {
+            double cv0 = 0;
+            UNR for (int j = 0; j < NX; j++) cv0 += AT(Ck, i * NX + j, b) * AT(c.v0, kpi * NX + j, b);
+            s = (AT(c.rkp, row, b) - AT(c.cv, row, b)) + beta * cv0;
+        } else {
+            s = (row == col) ? 1.0 : 0.0;
+            UNR for (int j = 0; j < NX; j++) s += AT(Ck, i * NX + j, b) * c.G[(size_t)(kpi * NX + j) * m + col];
+        }
+        Ms[row][col] = s;
+    }
+    if (lane < m) cs[lane] = AT(c.cv, lane, b);
+    __syncthreads();
+    for (int k = 0; k < m; k++) {
+        if (lane == 0) {
+            int pr = k;
+            double pv = fabs(Ms[k][k]);
+            for (int i = k + 1; i < m; i++) {
+                const double v = fabs(Ms[i][k]);
+                if (v > pv) { pv = v; pr = i; }
             }
+            prS = pr;
+        }
+        __syncthreads();
+        const int pr = prS;
+        if (lane <= m && lane >= k && pr != k) { const double t0 = Ms[k][lane]; Ms[k][lane] = Ms[pr][lane]; Ms[pr][lane] = t0; }
+        __syncthreads();
+        if (lane <= m && lane > k) {
+            const double piv = Ms[k][k], mk = Ms[k][lane];
+            for (int i = k + 1; i < m; i++) Ms[i][lane] -= (Ms[i][k] / piv) * mk;
+        }
+        __syncthreads();
+    }
+    if (lane == 0) {
+        for (int i = m - 1; i >= 0; i--) {
+            double s = Ms[i][m];
+            for (int q = i + 1; q < m; q++) s -= Ms[i][q] * xs[q];
+            xs[i] = s / Ms[i][i];
         }
     }
-    wide_lu_solve<LPB>(lds, m, lane);
-    UNR for (int j = 0; j < MC; j++) dv[j] = (j < m) ? RH(j) : 0.0;
-
-    // ||PSI dw||^2, dw = Z d - beta y0;  pieces of the control cost along the step
-    double dZd = 0, dp0 = 0, v0d = 0, cGd = 0, dGd = 0;
-    for (int i = 0; i < m; i++) {
-        double sz = 0, sgc = 0, sgd = 0;
-        UNR for (int j = 0; j < MC; j++)
-            if (j < m) {
-                sz += c.ZPZ[(size_t)i * m + j] * dv[j];
-                sgd += c.G[(size_t)i * m + j] * dv[j];
-                sgc += c.G[(size_t)i * m + j] * cv[j];
-            }
-        const double di = RH(i);
-        dZd += di * sz;
-        dGd += di * sgd;
-        cGd += di * sgc;
-        dp0 += di * AT(c.p0, i, b);
-        v0d += di * AT(c.v0, i, b);
+    __syncthreads();
+    if (lane < m) {  // rows of ZPZ d, G d, G c
+        double sz = 0, sgd = 0, sgc = 0;
+        for (int j = 0; j < m; j++) {
+            sz += c.ZPZ[(size_t)lane * m + j] * xs[j];
+            sgd += c.G[(size_t)lane * m + j] * xs[j];
+            sgc += c.G[(size_t)lane * m + j] * cs[j];
+        }
+        t1[lane] = sz; t2[lane] = sgd; t3[lane] = sgc;
+        AT(c.dvb, lane, b) = xs[lane];
     }
-    const double dun2 = dZd - 2 * beta * dp0 + beta * beta * pi;
-
-    double alpha = 1.0, cost = 0, bn = beta;
-    while (true) {  // BatchILQRCP.cpp:138-158
-        bn = (1 - alpha) * beta;
-        const double uru = c00 + (bn * bn - 1) * gam + 2 * bn * (v0c + alpha * v0d) + ((cGc + 2 * alpha * cGd) + alpha * alpha * dGd);
-        cost = wl_task_cost<S, MC>(d, a, c, b, bn, cv, dv, alpha) + uru;
-        if ((cost < cost0) || (alpha < 1e-3)) break;
-        alpha /= 2;
+    __syncthreads();
+    if (lane == 0) {
+        double dZd = 0, dp0 = 0, v0d = 0, cGd = 0, dGd = 0, v0c = 0, cGc = 0;
+        for (int i = 0; i < m; i++) {
+            const double di = xs[i], ci = cs[i], v0i = AT(c.v0, i, b);
+            dZd += di * t1[i];
+            dGd += di * t2[i];
+            cGd += di * t3[i];
+            cGc += ci * t3[i];
+            dp0 += di * AT(c.p0, i, b);
+            v0d += di * v0i;
+            v0c += v0i * ci;
+        }
+        AT(c.sc, 0, b) = v0c; AT(c.sc, 1, b) = cGc; AT(c.sc, 2, b) = v0d; AT(c.sc, 3, b) = cGd; AT(c.sc, 4, b) = dGd;
+        AT(c.sc, 5, b) = dZd - 2 * beta * dp0 + beta * beta * AT(c.scal, 2, b);
     }
+}
+
+// Backtracking with all step sizes at once: 16 lanes per instance, lane l tries alpha = 2^-l; the first lane whose cost improves
+// (or lane 10, alpha < 1e-3) wins (BatchILQRCP.cpp:138-158).
+template <class S, int MC>
+__global__ __launch_bounds__(64) void k_wl_linesearch(Bufs a, WArgs c) {
+    const DevDesc& d = *a.desc;
+    const int lane = threadIdx.x, l = lane & 15, bq = blockIdx.x * 4 + (lane >> 4);
+    const bool ok = bq < d.B && a.active[bq < d.B ? bq : 0];
+    const int b = ok ? bq : 0;
+    const int Bp = d.Bp, m = c.m;
+    double cv[MC], dv[MC];
+    UNR for (int j = 0; j < MC; j++) { cv[j] = (j < m) ? AT(c.cv, j, b) : 0.0; dv[j] = (j < m) ? AT(c.dvb, j, b) : 0.0; }
+    const double beta = c.beta[b], cost0 = a.cost[b];
+    const double alpha = ldexp(1.0, -(l < 11 ? l : 10)), bn = (1 - alpha) * beta;
+    const double uru = wl_uru(AT(c.scal, 0, b), AT(c.scal, 1, b), bn, alpha, AT(c.sc, 0, b), AT(c.sc, 2, b), AT(c.sc, 1, b), AT(c.sc, 3, b), AT(c.sc, 4, b));
+    const double cost = wl_task_cost<S, MC>(d, a, c, b, bn, cv, dv, alpha) + uru;
+    const bool take = (l < 11) && ((cost < cost0) || (alpha < 1e-3));
+    const unsigned long long mk = __ballot(take ? 1 : 0);
+    const int win = __ffs((unsigned)((mk >> (lane & 48)) & 0xffffull)) - 1;
+    if (!ok || l != win) return;
     UNR for (int j = 0; j < MC; j++)
         if (j < m) AT(c.cv, j, b) = cv[j] + alpha * dv[j];
     c.beta[b] = bn;
@@ -309,6 +338,7 @@ __global__ __launch_bounds__(LPB) void k_wl_iter(Bufs a, WArgs c) {
         a.alpha_trace[(size_t)c.it * Bp + b] = alpha;
     }
     a.cost[b] = cost;
+    const double dun2 = AT(c.sc, 5, b);
     if (c.early_stop && alpha * sqrt(dun2 > 0 ? dun2 : 0.0) < 1e-3) a.active[b] = 0;  // :167
 }
 
@@ -559,20 +589,26 @@ __global__ __launch_bounds__(64) void k_wt_solve(Bufs a, WTArgs c) {
     if (lane == 0) c.dun2[b] = dn;
 }
 
+// Backtracking with all step sizes at once: 16 lanes per instance, lane l rolls out u + 2^-l du (BatchILQR.cpp:138-158: the first
+// alpha whose cost improves wins, alpha < 1e-3 is accepted anyway).  On the time systems the search often ends at its floor, so
+// the chain a lane walks is one rollout instead of eleven.
 template <class S>
 __global__ __launch_bounds__(64) void k_wt_linesearch(Bufs a, WTArgs c) {
     constexpr int NX = S::NX, NU = S::NU;
     const DevDesc& d = *a.desc;
-    const int b = blockIdx.x * 64 + threadIdx.x;
-    if (b >= d.B || !a.active[b]) return;
+    const int lane = threadIdx.x, l = lane & 15, bq = blockIdx.x * 4 + (lane >> 4);
+    const bool ok = bq < d.B && a.active[bq < d.B ? bq : 0];
+    const int b = ok ? bq : 0;
     const int Bp = d.Bp, T = d.T;
     double* U = a.U[0];
     const double* DU = a.U[1];
     const double cost0 = a.cost[b];
-    double alpha = 1.0, cost = 0;
-    while (true) {  // BatchILQR.cpp:138-158
+    const double alpha = ldexp(1.0, -(l < 11 ? l : 10));
+    double cost;
+    {
         double x[NX], xp[NX], u[NU], xn[NX];
         init_state<S>(d, a, b, x);
+        UNR for (int i = 0; i < NX; i++) xp[i] = x[i];
         double cost_e = 0, cost_u = 0, cost_l = 0;
         int kpi = 0;
         auto kp_here = [&](int i) {
@@ -597,10 +633,14 @@ __global__ __launch_bounds__(64) void k_wt_linesearch(Bufs a, WTArgs c) {
             if (kpi < d.n_kp && d.kp_t[kpi] == s + 1) kp_here(s + 1);
         }
         cost = cost_e + cost_u + cost_l;
-        if ((cost < cost0) || (alpha < 1e-3)) break;
-        alpha /= 2;
     }
-    for (int s = 0; s < (T - 1) * NU; s++) AT(U, s, b) += alpha * AT(DU, s, b);
+    const bool take = (l < 11) && ((cost < cost0) || (alpha < 1e-3));
+    const unsigned long long mk = __ballot(take ? 1 : 0);
+    const int win = __ffs((unsigned)((mk >> (lane & 48)) & 0xffffull)) - 1;
+    if (!ok) return;
+    const double aw = ldexp(1.0, -win);
+    for (int s = l; s < (T - 1) * NU; s += 16) AT(U, s, b) += aw * AT(DU, s, b);  // u = utmp of the winner, the 16 lanes share the copy
+    if (l != win) return;
     a.alpha[b] = alpha;
     a.iters[b] = c.it + 1;
     a.status[b] = (isfinite(cost) ? 0 : 1) | ((alpha < 1e-3) ? 2 : 0);
@@ -685,8 +725,8 @@ static bool spd_inverse(std::vector<double>& A, int n) {
 
 // LTI systems.  psi == nullptr: identity basis.
 template <class S, int MC>
-static int run_wl(BatchWideState& st, const DevDesc& h, Bufs& bufs, const double* psi, int Kw, int nb_iter, int early_stop, hipStream_t stream,
-                  std::string& err) {
+static int run_wl(BatchWideState& st, const DevDesc& h, Bufs& bufs, const double* psi, int Kw, int nb_iter, int early_stop, bool u0_zero,
+                  hipStream_t stream, std::string& err) {
     constexpr int NX = S::NX, NU = S::NU, ND = S::ND;
     const int B = h.B, Bp = h.Bp, T = h.T, nkp = h.n_kp, m = nkp * NX, N = (T - 1) * NU;
     const bool ident = psi == nullptr;
@@ -706,7 +746,8 @@ static int run_wl(BatchWideState& st, const DevDesc& h, Bufs& bufs, const double
                   w_alloc(st, &st.PZ, (size_t)N * m, stream) && w_alloc(st, &st.xbk, (size_t)nkp * 2 * NX * Bp, stream) &&
                   w_alloc(st, &st.av, (size_t)nkp * 2 * NX * Bp, stream) && w_alloc(st, &st.v0, (size_t)m * Bp, stream) && w_alloc(st, &st.p0, (size_t)m * Bp, stream) &&
                   w_alloc(st, &st.scal, (size_t)3 * Bp, stream) && w_alloc(st, &st.cv, (size_t)m * Bp, stream) && w_alloc(st, &st.beta, (size_t)Bp, stream) &&
-                  w_alloc(st, &st.Ckp, (size_t)nkp * NX * NX * Bp, stream) && w_alloc(st, &st.rkp, (size_t)m * Bp, stream);
+                  w_alloc(st, &st.Ckp, (size_t)nkp * NX * NX * Bp, stream) && w_alloc(st, &st.rkp, (size_t)m * Bp, stream) &&
+                  w_alloc(st, &st.dvb, (size_t)m * Bp, stream) && w_alloc(st, &st.sc, (size_t)6 * Bp, stream);
         if (ok && !ident)
             ok = w_alloc(st, &st.u0hat, (size_t)N * Bp, stream) && w_alloc(st, &st.g0, (size_t)Kw * Bp, stream) && w_alloc(st, &st.y0, (size_t)Kw * Bp, stream) &&
                  w_alloc(st, &st.psi, (size_t)N * Kw, stream) && w_alloc(st, &st.h0inv, (size_t)Kw * Kw, stream);
@@ -819,25 +860,23 @@ static int run_wl(BatchWideState& st, const DevDesc& h, Bufs& bufs, const double
     WArgs c;
     c.G = st.G; c.Et = st.Et; c.ZPZ = st.ZPZ; c.PZ = st.PZ;
     c.xbk = st.xbk; c.av = st.av; c.v0 = st.v0; c.p0 = st.p0; c.scal = st.scal; c.cv = st.cv; c.beta = st.beta;
-    c.Ckp = st.Ckp; c.rkp = st.rkp;
+    c.Ckp = st.Ckp; c.rkp = st.rkp; c.dvb = st.dvb; c.sc = st.sc;
     c.u0hat = ident ? bufs.U0 : st.u0hat;
     c.m = m; c.it = 0; c.early_stop = early_stop;
     const dim3 grid((B + 63) / 64), block(64);
-    if (!ident) {  // u0^ = PSI (H0^-1 (PSI'R u0))
+    if (!ident && u0_zero) {  // the projection of zero controls
+        if (hipMemsetAsync(st.u0hat, 0, (size_t)N * Bp * sizeof(double), stream) != hipSuccess) { err = "wide-basis batch solve: memset failed"; return 1; }
+    } else if (!ident) {  // u0^ = PSI (H0^-1 (PSI'R u0))
         hipLaunchKernelGGL(k_w_g0, dim3((B + 63) / 64, Kw), block, 0, stream, st.psi, bufs.U0, bufs.desc, st.g0, N, Kw, NU);
         hipLaunchKernelGGL(k_w_matvec, dim3((B + 63) / 64, Kw), block, 0, stream, st.h0inv, st.g0, bufs.desc, st.y0, Kw, Kw);
         hipLaunchKernelGGL(k_w_matvec, dim3((B + 63) / 64, N), block, 0, stream, st.psi, st.y0, bufs.desc, st.u0hat, N, Kw);
     }
-    hipLaunchKernelGGL((k_wl_init<S, MC>), grid, block, 0, stream, bufs, c);
-    constexpr int LPB = MC <= 16 ? 32 : 16;
-    const size_t lds_it = sizeof(double) * m * (m + 1) * LPB;
-    if (hipFuncSetAttribute((const void*)k_wl_iter<S, MC, LPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_it) != hipSuccess) {
-        err = "wide-basis batch solve: cannot reserve LDS";
-        return 1;
-    }
+    hipLaunchKernelGGL((k_wl_init<S, MC>), dim3((B + 64 / MC - 1) / (64 / MC)), dim3(64), 0, stream, bufs, c);
     for (int it = 0; it < nb_iter; it++) {
         c.it = it;
-        hipLaunchKernelGGL((k_wl_iter<S, MC, LPB>), dim3((B + LPB - 1) / LPB), dim3(LPB), lds_it, stream, bufs, c);
+        hipLaunchKernelGGL((k_wl_linearize<S, MC>), dim3((B + 15) / 16, nkp), dim3(16), 0, stream, bufs, c);
+        hipLaunchKernelGGL((k_wl_solve<S, MC>), dim3(B), dim3(64), 0, stream, bufs, c);
+        hipLaunchKernelGGL((k_wl_linesearch<S, MC>), dim3((B + 3) / 4), dim3(64), 0, stream, bufs, c);
     }
     hipLaunchKernelGGL((k_wl_controls<S, MC>), dim3((B + 63) / 64, T - 1), block, 0, stream, bufs, c);
     hipLaunchKernelGGL((k_wide_final<S>), grid, block, 0, stream, bufs);
@@ -846,11 +885,11 @@ static int run_wl(BatchWideState& st, const DevDesc& h, Bufs& bufs, const double
 }
 
 template <class S>
-static int run_wl_m(BatchWideState& st, const DevDesc& h, Bufs& bufs, const double* psi, int Kw, int nb_iter, int early_stop, hipStream_t stream,
-                    std::string& err) {
+static int run_wl_m(BatchWideState& st, const DevDesc& h, Bufs& bufs, const double* psi, int Kw, int nb_iter, int early_stop, bool u0_zero,
+                    hipStream_t stream, std::string& err) {
     const int m = h.n_kp * S::NX;
-    if (m <= 16) return run_wl<S, 16>(st, h, bufs, psi, Kw, nb_iter, early_stop, stream, err);
-    if (m <= 32) return run_wl<S, 32>(st, h, bufs, psi, Kw, nb_iter, early_stop, stream, err);
+    if (m <= 16) return run_wl<S, 16>(st, h, bufs, psi, Kw, nb_iter, early_stop, u0_zero, stream, err);
+    if (m <= 32) return run_wl<S, 32>(st, h, bufs, psi, Kw, nb_iter, early_stop, u0_zero, stream, err);
     err = "wide-basis batch solve: n_keypoints * n_x must not exceed 32";
     return 1;
 }
@@ -880,7 +919,7 @@ static int run_wt(BatchWideState& st, const DevDesc& h, Bufs& bufs, int nb_iter,
         c.it = it;
         hipLaunchKernelGGL((k_wt_roll<S>), grid, block, 0, stream, bufs, c);
         hipLaunchKernelGGL((k_wt_solve<S, MC>), dim3(B), block, 0, stream, bufs, c);
-        hipLaunchKernelGGL((k_wt_linesearch<S>), grid, block, 0, stream, bufs, c);
+        hipLaunchKernelGGL((k_wt_linesearch<S>), dim3((B + 3) / 4), dim3(64), 0, stream, bufs, c);
     }
     hipLaunchKernelGGL((k_wide_final<S>), grid, block, 0, stream, bufs);
     if (hipGetLastError() != hipSuccess) { err = "wide-basis batch solve: kernel launch failed"; return 1; }
@@ -897,16 +936,16 @@ static int run_wt_m(BatchWideState& st, const DevDesc& h, Bufs& bufs, int nb_ite
 }
 
 int batchwide_solve(BatchWideState& st, const DevDesc& h, Bufs& bufs, int nx, int nu, const double* psi_host, int Kw, int nb_iter, int early_stop,
-                    hipStream_t stream, std::string& err) {
+                    bool u0_zero, hipStream_t stream, std::string& err) {
     (void)nx;
     const int N = (h.T - 1) * nu;
     if (nb_iter < 0) { err = "nb_iter < 0"; return 1; }
     if (h.n_kp <= 0) { err = "wide-basis batch solve: the system has no keypoint"; return 1; }
     if (!psi_host) Kw = N;
     if (Kw <= 0 || Kw > N) { err = "wide-basis batch solve: Kw must be in 1 .. (T-1) n_u"; return 1; }
-    if (h.kind == 0 && h.nd == 1) return run_wl_m<Sys<0, 1>>(st, h, bufs, psi_host, Kw, nb_iter, early_stop, stream, err);
-    if (h.kind == 0 && h.nd == 2) return run_wl_m<Sys<0, 2>>(st, h, bufs, psi_host, Kw, nb_iter, early_stop, stream, err);
-    if (h.kind == 2) return run_wl_m<Sys<2, 1>>(st, h, bufs, psi_host, Kw, nb_iter, early_stop, stream, err);
+    if (h.kind == 0 && h.nd == 1) return run_wl_m<Sys<0, 1>>(st, h, bufs, psi_host, Kw, nb_iter, early_stop, u0_zero, stream, err);
+    if (h.kind == 0 && h.nd == 2) return run_wl_m<Sys<0, 2>>(st, h, bufs, psi_host, Kw, nb_iter, early_stop, u0_zero, stream, err);
+    if (h.kind == 2) return run_wl_m<Sys<2, 1>>(st, h, bufs, psi_host, Kw, nb_iter, early_stop, u0_zero, stream, err);
     if (psi_host) { err = "wide-basis batch solve: on time systems only the identity basis (ilqr_solve_batch) is supported for Kw > 16"; return 1; }
     if (h.kind == 1 && h.nd == 1) return run_wt_m<Sys<1, 1>>(st, h, bufs, nb_iter, early_stop, stream, err);
     if (h.kind == 1 && h.nd == 2) return run_wt_m<Sys<1, 2>>(st, h, bufs, nb_iter, early_stop, stream, err);

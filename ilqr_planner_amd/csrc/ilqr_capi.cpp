@@ -52,6 +52,7 @@ struct ilqr_problem {
     size_t staging_elems = 0;
     int last_nb_iter = 0;
     bool has_controls = false, has_state = false;
+    bool u0_zero = false;  // the initial controls given from the host are all zero (lets the wide-basis batch solver skip their projection)
     BatchCPState cp;
     BatchWideState cpw;
 };
@@ -404,6 +405,13 @@ static int set_controls(ilqr_problem* p, const double* U0, bool dev) {
     if (!U0) return fail(p->ctx, "U0 is required");
     if (upload(p, U0, dev, (double*)p->bufs.U0, (p->T - 1) * p->dims.n_u)) return 1;
     p->has_controls = true;
+    p->u0_zero = false;
+    if (!dev) {
+        const size_t n = (size_t)p->B * (p->T - 1) * p->dims.n_u;
+        size_t i = 0;
+        while (i < n && U0[i] == 0.0) i++;
+        p->u0_zero = (i == n);
+    }
     return 0;
 }
 extern "C" int ilqr_problem_set_controls(ilqr_problem* p, const double* U0) { return set_controls(p, U0, false); }
@@ -582,7 +590,7 @@ extern "C" int ilqr_solve_batch_cp(ilqr_problem* p, const double* psi, int Kw, i
     if (ensure_trace(p, nb_iter)) return 1;
     p->last_nb_iter = nb_iter;
     if (psi && Kw > 16) {  // wide basis: low-rank form of the normal equations (ilqr_batchwide.hip)
-        if (batchwide_solve(p->cpw, p->hdesc, p->bufs, p->dims.n_x, p->dims.n_u, psi, Kw, nb_iter, early_stop, c->stream, err)) return fail(c, err);
+        if (batchwide_solve(p->cpw, p->hdesc, p->bufs, p->dims.n_x, p->dims.n_u, psi, Kw, nb_iter, early_stop, p->u0_zero, c->stream, err)) return fail(c, err);
         return 0;
     }
     if (batchcp_solve(p->cp, p->hdesc, p->bufs, p->dims.n_x, p->dims.n_u, p->dims.n_f, p->dims.n_Q, psi, Kw, nb_iter, early_stop, c->stream, err))
@@ -597,7 +605,7 @@ extern "C" int ilqr_solve_batch(ilqr_problem* p, int nb_iter, int early_stop) {
     std::string err;
     if (ensure_trace(p, nb_iter)) return 1;
     p->last_nb_iter = nb_iter;
-    if (batchwide_solve(p->cpw, p->hdesc, p->bufs, p->dims.n_x, p->dims.n_u, nullptr, 0, nb_iter, early_stop, c->stream, err)) return fail(c, err);
+    if (batchwide_solve(p->cpw, p->hdesc, p->bufs, p->dims.n_x, p->dims.n_u, nullptr, 0, nb_iter, early_stop, p->u0_zero, c->stream, err)) return fail(c, err);
     return 0;
 }
 
