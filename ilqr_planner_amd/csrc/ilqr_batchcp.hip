@@ -30,18 +30,19 @@ namespace ilqr {
 #endif
 constexpr int LPB = CP_LPB;
 
+// KWP lanes per instance: lane q owns column q of W = Su PSI (n_x values in registers) and of PSI'R u, and reads its entries of the
+// basis rows as coalesced vector loads (with one lane per instance they are uniform -> one scalar-load latency per entry: 24 us per
+// step on the 2nd-order time system).  All lanes walk the rollout and the keypoint evaluation; lane 0 writes the shared results.
 template <class S, int KWP>
-__global__ __launch_bounds__(LPB) void k_cp_linearize(Bufs a, CPArgs c) {
-    constexpr int NX = S::NX, NU = S::NU;
-    extern __shared__ double lds[];
+__global__ __launch_bounds__(64) void k_cp_linearize(Bufs a, CPArgs c) {
+    constexpr int NX = S::NX, NU = S::NU, IPB = 64 / KWP;
+    static_assert(64 % KWP == 0, "KWP lanes per instance");
     const DevDesc& d = *a.desc;
-    const int lane = threadIdx.x, b = blockIdx.x * LPB + lane;
+    const int q = threadIdx.x % KWP, b = blockIdx.x * IPB + threadIdx.x / KWP;
     if (b >= d.B || !a.active[b]) return;
     const int Bp = d.Bp, T = d.T;
-#define WL(r, q) lds[((r) * KWP + (q)) * LPB + lane]
-    for (int i = 0; i < NX * KWP; i++) lds[i * LPB + lane] = 0;
-    double x[NX], xp[NX], u[NU], gu[KWP];
-    UNR for (int q = 0; q < KWP; q++) gu[q] = 0;
+    double W[NX], x[NX], xp[NX], u[NU], gu = 0;
+    UNR for (int r = 0; r < NX; r++) W[r] = 0;
     init_state<S>(d, a, b, x);
     UNR for (int i = 0; i < NX; i++) xp[i] = x[i];
     double cost_e = 0, cost_u = 0, cost_l = 0;
@@ -57,49 +58,64 @@ __global__ __launch_bounds__(LPB) void k_cp_linearize(Bufs a, CPArgs c) {
         UNR for (int r = 0; r < S::NF; r++) tg[r] = AT(a.kp_tg, kpi * S::NF + r, b);
         cost_e += kp_cost<S>(d, kpi, tg, x, nullptr);
         UNR for (int r = 0; r < NX; r++) cost_l += ql[r] * Ld[r] * ql[r];
-        double* Ck = c.Ckp + (size_t)kpi * NX * NX * Bp;
-        double* rk = c.rkp + (size_t)kpi * NX * Bp;
         double* Wk = c.Wkp + (size_t)kpi * NX * KWP * Bp;
-        UNR for (int r = 0; r < NX; r++) {
-            UNR for (int s = 0; s < NX; s++) AT(Ck, r * NX + s, b) = lxx[r][s] + ((r == s) ? Ld[r] : 0.0);
-            AT(rk, r, b) = -lx[r] + Ld[r] * ql[r];
+        UNR for (int r = 0; r < NX; r++) AT(Wk, r * KWP + q, b) = W[r];
+        if (q == 0) {
+            double* Ck = c.Ckp + (size_t)kpi * NX * NX * Bp;
+            double* rk = c.rkp + (size_t)kpi * NX * Bp;
+            UNR for (int r = 0; r < NX; r++) {
+                UNR for (int s = 0; s < NX; s++) AT(Ck, r * NX + s, b) = lxx[r][s] + ((r == s) ? Ld[r] : 0.0);
+                AT(rk, r, b) = -lx[r] + Ld[r] * ql[r];
+            }
         }
-        for (int e = 0; e < NX * KWP; e++) AT(Wk, e, b) = lds[e * LPB + lane];
         kpi++;
     };
 
     if (kpi < d.n_kp && d.kp_t[kpi] == 0) record(0);
-    for (int s = 0; s < T - 1; s++) {
-        UNR for (int i = 0; i < NU; i++) u[i] = AT(U, s * NU + i, b);
-        UNR for (int i = 0; i < NU; i++) cost_u += u[i] * d.R_diag[i] * u[i];
-        UNR for (int i = 0; i < NU; i++) {
-            const double ru = d.R_diag[i] * u[i];
-            UNR for (int q = 0; q < KWP; q++) gu[q] += PSI(s * NU + i, q) * ru;
+    // the controls and basis rows of G steps are fetched together and consumed before any branch: one memory latency per group.
+    // Basis row-set s+1 serves the W update of step s and the PSI'R u term of step s+1.
+    constexpr int G = 4;
+    for (int s0 = 0; s0 < T - 1; s0 += G) {
+        double ug[G][NU], pg[G + 1][NU];
+        UNR for (int k = 0; k < G; k++) {
+            const int s = (s0 + k < T - 1) ? s0 + k : T - 2;
+            UNR for (int i = 0; i < NU; i++) ug[k][i] = AT(U, s * NU + i, b);
         }
-        StepAB<S> ab;
-        double xn[NX];
-        step_ab<S>(d, x, u, xn, ab);
-        UNR for (int i = 0; i < NX; i++) { xp[i] = x[i]; x[i] = xn[i]; }
-        const int i = s + 1;
-        if (kpi < d.n_kp && d.kp_t[kpi] == i) record(i);
-        if (i <= T - 2) {  // W_{i+1} = A_i W_i + B_i PSI_i
-            for (int q = 0; q < KWP; q++) {
-                if (S::ND == 2) { UNR for (int r = 0; r < DOF; r++) WL(r, q) += ab.dt * WL(DOF + r, q); }
-                UNR for (int r = 0; r < DOF; r++) {
-                    const double ps = PSI(i * NU + r, q);
-                    if (S::ND == 1) WL(r, q) += ab.dt * ps;
-                    else { WL(r, q) += ab.hdt2 * ps; WL(DOF + r, q) += ab.dt * ps; }
-                }
-                if (S::TM) {
-                    const double pl = PSI(i * NU + NU - 1, q);
-                    UNR for (int r = 0; r < NX; r++) WL(r, q) += ab.bc[r] * pl;
+        UNR for (int k = 0; k <= G; k++) {
+            const int s = (s0 + k < T - 1) ? s0 + k : T - 2;
+            UNR for (int i = 0; i < NU; i++) pg[k][i] = PSI(s * NU + i, q);
+        }
+        UNR for (int k = 0; k < G; k++) { UNR for (int i = 0; i < NU; i++) asm volatile("" : "+v"(ug[k][i])); }
+        UNR for (int k = 0; k <= G; k++) { UNR for (int i = 0; i < NU; i++) asm volatile("" : "+v"(pg[k][i])); }
+        UNR for (int k = 0; k < G; k++) {
+            const int s = s0 + k;
+            if (s < T - 1) {
+                UNR for (int i = 0; i < NU; i++) u[i] = ug[k][i];
+                UNR for (int i = 0; i < NU; i++) cost_u += u[i] * d.R_diag[i] * u[i];
+                UNR for (int i = 0; i < NU; i++) gu += pg[k][i] * (d.R_diag[i] * u[i]);
+                StepAB<S> ab;
+                double xn[NX];
+                step_ab<S>(d, x, u, xn, ab);
+                UNR for (int i = 0; i < NX; i++) { xp[i] = x[i]; x[i] = xn[i]; }
+                const int i = s + 1;
+                if (kpi < d.n_kp && d.kp_t[kpi] == i) record(i);
+                if (i <= T - 2) {  // W_{i+1} = A_i W_i + B_i PSI_i
+                    if (S::ND == 2) { UNR for (int r = 0; r < DOF; r++) W[r] += ab.dt * W[DOF + r]; }
+                    UNR for (int r = 0; r < DOF; r++) {
+                        const double ps = pg[k + 1][r];
+                        if (S::ND == 1) W[r] += ab.dt * ps;
+                        else { W[r] += ab.hdt2 * ps; W[DOF + r] += ab.dt * ps; }
+                    }
+                    if (S::TM) {
+                        const double pl = pg[k + 1][NU - 1];
+                        UNR for (int r = 0; r < NX; r++) W[r] += ab.bc[r] * pl;
+                    }
                 }
             }
         }
     }
-    a.cost[b] = cost_e + cost_u + cost_l;  // cost0 of this iteration (BatchILQRCP.cpp:135)
-    UNR for (int q = 0; q < KWP; q++) AT(c.gu, q, b) = gu[q];
-#undef WL
+    AT(c.gu, q, b) = gu;
+    if (q == 0) a.cost[b] = cost_e + cost_u + cost_l;  // cost0 of this iteration (BatchILQRCP.cpp:135)
 }
 
 template <class S, int KWP>
@@ -251,69 +267,21 @@ __global__ __launch_bounds__(64) void k_cp_solve_w(Bufs a, CPArgs c) {
     if (lane < KWP) AT(c.dw, lane, b) = xs[lane];
 }
 
+// du = PSI dw for every control entry (a.U[1]), one lane per (instance, step): the line search then needs no basis at all
 template <class S, int KWP>
-__global__ __launch_bounds__(LPB) void k_cp_linesearch(Bufs a, CPArgs c) {
-    constexpr int NX = S::NX, NU = S::NU;
+__global__ __launch_bounds__(64) void k_cp_du(Bufs a, CPArgs c) {
+    constexpr int NU = S::NU;
     const DevDesc& d = *a.desc;
-    const int b = blockIdx.x * LPB + threadIdx.x;
+    const int b = blockIdx.x * 64 + threadIdx.x, s = blockIdx.y;
     if (b >= d.B || !a.active[b]) return;
-    const int Bp = d.Bp, T = d.T;
+    const int Bp = d.Bp;
     double dw[KWP];
     UNR for (int q = 0; q < KWP; q++) dw[q] = AT(c.dw, q, b);
-    double* U = a.U[0];
-    const double cost0 = a.cost[b];
-    double alpha = 1.0, cost = 0, dun2 = 0;
-    bool first = true;
-    while (true) {  // BatchILQRCP.cpp:138-158
-        double x[NX], xp[NX], u[NU], xn[NX];
-        init_state<S>(d, a, b, x);
-        double cost_e = 0, cost_u = 0, cost_l = 0;
-        int kpi = 0;
-        auto kp_here = [&](int i) {
-            double tg[S::NF];
-            UNR for (int r = 0; r < S::NF; r++) tg[r] = AT(a.kp_tg, kpi * S::NF + r, b);
-            cost_e += kp_cost<S>(d, kpi, tg, x, nullptr);
-            if (i > 0) {
-                double Ld[NX], ql[NX];
-                limit_terms<S>(d, xp, Ld, ql);
-                UNR for (int r = 0; r < NX; r++) cost_l += ql[r] * Ld[r] * ql[r];
-            }
-            kpi++;
-        };
-        if (kpi < d.n_kp && d.kp_t[kpi] == 0) kp_here(0);
-        for (int s = 0; s < T - 1; s++) {
-            UNR for (int i = 0; i < NU; i++) {
-                double du = 0;
-                UNR for (int q = 0; q < KWP; q++) du += PSI(s * NU + i, q) * dw[q];
-                if (first) dun2 += du * du;
-                u[i] = AT(U, s * NU + i, b) + alpha * du;
-                cost_u += u[i] * d.R_diag[i] * u[i];
-            }
-            dyn_step<S>(d, x, u, xn);
-            UNR for (int i = 0; i < NX; i++) { xp[i] = x[i]; x[i] = xn[i]; }
-            if (kpi < d.n_kp && d.kp_t[kpi] == s + 1) kp_here(s + 1);
-        }
-        first = false;
-        cost = cost_e + cost_u + cost_l;
-        if ((cost < cost0) || (alpha < 1e-3)) break;
-        alpha /= 2;
+    UNR for (int i = 0; i < NU; i++) {
+        double du = 0;
+        UNR for (int q = 0; q < KWP; q++) du += PSI(s * NU + i, q) * dw[q];
+        AT(a.U[1], s * NU + i, b) = du;
     }
-    for (int s = 0; s < T - 1; s++) {  // u = utmp
-        UNR for (int i = 0; i < NU; i++) {
-            double du = 0;
-            UNR for (int q = 0; q < KWP; q++) du += PSI(s * NU + i, q) * dw[q];
-            AT(U, s * NU + i, b) += alpha * du;
-        }
-    }
-    a.alpha[b] = alpha;
-    a.iters[b] = c.it + 1;
-    a.status[b] = (isfinite(cost) ? 0 : 1) | ((alpha < 1e-3) ? 2 : 0);
-    if (a.cost_trace) {
-        a.cost_trace[(size_t)c.it * Bp + b] = cost0;  // the reference prints the PRE-step cost (BatchILQRCP.cpp:160)
-        a.alpha_trace[(size_t)c.it * Bp + b] = alpha;
-    }
-    a.cost[b] = cost;
-    if (c.early_stop && alpha * sqrt(dun2) < 1e-3) a.active[b] = 0;  // :167
 }
 
 // controls <- U0, solver state reset
@@ -582,10 +550,8 @@ static int run_cp(BatchCPState& st, const DevDesc& h, Bufs& bufs, int nb_iter, i
     constexpr int NX = S::NX;
     const int B = h.B;
     const dim3 grid((B + LPB - 1) / LPB), block(LPB);
-    const size_t lds_w = sizeof(double) * NX * KWP * LPB, lds_h = sizeof(double) * KWP * KWP * LPB;
-    if (lds_w > 160 * 1024 || lds_h > 160 * 1024) { err = "ilqr_solve_batch_cp: basis too wide for the LDS tiles (n_x * Kw <= 320, Kw <= 16)"; return 1; }
-    if (hipFuncSetAttribute((const void*)k_cp_linearize<S, KWP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w) != hipSuccess ||
-        hipFuncSetAttribute((const void*)k_cp_solve<S, KWP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h) != hipSuccess) {
+    const size_t lds_h = sizeof(double) * KWP * KWP * LPB;
+    if (hipFuncSetAttribute((const void*)k_cp_solve<S, KWP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h) != hipSuccess) {
         err = "ilqr_solve_batch_cp: cannot reserve LDS";
         return 1;
     }
@@ -597,10 +563,13 @@ static int run_cp(BatchCPState& st, const DevDesc& h, Bufs& bufs, int nb_iter, i
     hipLaunchKernelGGL((k_cp_init<S>), dim3((B + 255) / 256), dim3(256), 0, stream, bufs);
     for (int it = 0; it < nb_iter; it++) {
         c.it = it;
-        hipLaunchKernelGGL((k_cp_linearize<S, KWP>), grid, block, lds_w, stream, bufs, c);
+        hipLaunchKernelGGL((k_cp_linearize<S, KWP>), dim3((B + 64 / KWP - 1) / (64 / KWP)), dim3(64), 0, stream, bufs, c);
         if (wave_solve) hipLaunchKernelGGL((k_cp_solve_w<S, KWP>), dim3(B), dim3(64), 0, stream, bufs, c);
         else hipLaunchKernelGGL((k_cp_solve<S, KWP>), grid, block, lds_h, stream, bufs, c);
-        hipLaunchKernelGGL((k_cp_linesearch<S, KWP>), grid, block, 0, stream, bufs, c);
+        hipLaunchKernelGGL((k_cp_du<S, KWP>), dim3((B + 63) / 64, h.T - 1), dim3(64), 0, stream, bufs, c);
+        BTArgs bt;
+        bt.it = it; bt.early_stop = early_stop;
+        hipLaunchKernelGGL((k_bt_linesearch<S>), dim3((B + 3) / 4), dim3(64), 0, stream, bufs, bt);
     }
     hipLaunchKernelGGL((k_cp_final<S>), grid, block, 0, stream, bufs);
     if (hipGetLastError() != hipSuccess) { err = "ilqr_solve_batch_cp: kernel launch failed"; return 1; }
