@@ -1,4 +1,5 @@
-"""Per-iteration cost differences GPU (low-rank batch solve) vs oracle (dense), identity basis."""
+"""[test tooling: compares the GPU path with the oracle; lives under tests/ because only tests may use oracle/]
+Per-iteration cost differences GPU (low-rank batch solve) vs oracle (dense), identity basis."""
 import sys
 import numpy as np
 sys.path.insert(0, ".")

@@ -1,6 +1,7 @@
-"""Diagnostic: per-instance comparison of the HIP path with the oracle on a seeded batch (run on the GPU box)."""
+"""[test tooling: compares the GPU path with the oracle; lives under tests/ because only tests may use oracle/]
+Diagnostic: per-instance comparison of the HIP path with the oracle on a seeded batch (run on the GPU box)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from ilqr_planner_amd import capi, workloads
 from tests.helpers import oracle_solve_instance, panda_segs

@@ -1,8 +1,9 @@
-"""Cost trace of one tutorial case at full precision: HIP path (whatever ILQR_HIP_PATH / ILQR_BWD select) next to the oracle."""
+"""[test tooling: compares the GPU path with the oracle; lives under tests/ because only tests may use oracle/]
+Cost trace of one tutorial case at full precision: HIP path (whatever ILQR_HIP_PATH / ILQR_BWD select) next to the oracle."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))        # tests/
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))  # repo root
 from helpers import golden
 import test_gpu_parity as tg
 from ilqr_planner_amd import capi
