@@ -69,19 +69,25 @@ struct LimRegs {
 
 // ------------------------------------------------------------------------------------------------ forward, alpha-parallel
 
+// instances per workgroup of k_forward_tile: 4 (one wave, 11 KB of LDS for the 2nd-order time system) gives 1024 workgroups
+// at B = 4096 -- four per CU, whose barriers and load latencies overlap -- where 16 gave one per CU (C4: 0.85 -> 0.70 ms; 8: 0.75, 2: 1.36)
+#ifndef FT_TI
+#define FT_TI 4
+#endif
 template <class S, bool APPLY>
-__global__ __launch_bounds__(256) void k_forward_tile(Bufs a, FwdArgs f) {
+__global__ __launch_bounds__(FT_TI * 16) void k_forward_tile(Bufs a, FwdArgs f) {
     constexpr int NX = S::NX, NU = S::NU, NK = NU * NX;
     constexpr int NC = NK + NU + NX + NU;          // doubles per instance-step: K | d | xbar | ubar
     constexpr int NO = NX + NU;                    // doubles written per instance-step: x | u
     constexpr int PF = 4;                          // prefetch distance in timesteps
-    __shared__ double s_in[2][NC][16];
-    __shared__ double s_out[2][NO][16];
-    __shared__ int s_wr[16];
+    constexpr int TI = FT_TI, NT = TI * 16;        // instances per workgroup (x 16 step sizes each) and its threads
+    __shared__ double s_in[2][NC][TI];
+    __shared__ double s_out[2][NO][TI];
+    __shared__ int s_wr[TI];
 
     const DevDesc& d = *a.desc;
     const int tid = threadIdx.x, il = tid >> 4, ai = tid & 15;
-    const int b0 = xcd_tile() * 16, b = b0 + il;
+    const int b0 = xcd_tile() * TI, b = b0 + il;
     const int Bp = d.Bp, T = d.T, B = d.B;
 
     // SPEC: lane `ai` tries alpha = 2^-ai; the lane whose index equals the instance's PREDICTED winner (the winner of
@@ -116,10 +122,10 @@ __global__ __launch_bounds__(256) void k_forward_tile(Bufs a, FwdArgs f) {
     // xbar | ubar: component (tid >> 4) + 16 j of instance tid & 15 (16 instances of a row = one 128-byte line).
     // Every load is unconditional (timesteps beyond the end re-read the last one): see ilqr_kernels_coop.hip on vmcnt.
     constexpr int ROWP = kd_rowp(NX), RS = NU * ROWP;
-    constexpr int NLG = (16 * RS + 255) / 256;           // gain loads per thread per step
-    constexpr int NLX = ((NX + NU) * 16 + 255) / 256;    // xbar/ubar loads per thread per step
+    constexpr int NLG = (TI * RS + NT - 1) / NT;         // gain loads per thread per step
+    constexpr int NLX = ((NX + NU) * TI + NT - 1) / NT;  // xbar/ubar loads per thread per step
     constexpr int NLD = NLG + NLX;
-    const int li = tid & 15, lb = b0 + li, lc0 = tid >> 4;
+    const int li = tid % TI, lb = b0 + li, lc0 = tid / TI;
     const int lcur = a.cur[lb];
     const double* Xc = a.X[lcur];
     const double* Uc = a.U[lcur];
@@ -127,12 +133,12 @@ __global__ __launch_bounds__(256) void k_forward_tile(Bufs a, FwdArgs f) {
     const size_t gstep = (size_t)Bp * RS;
     int goff[NLG], gdst[NLG];  // flat source offset (clamped into the run) and LDS destination (-1: padding / out of range)
     UNR for (int q = 0; q < NLG; q++) {
-        const int fl = tid + 256 * q;
-        const bool in = fl < 16 * RS;
+        const int fl = tid + NT * q;
+        const bool in = fl < TI * RS;
         const int flc = in ? fl : 0;
         const int inst = flc / RS, w = flc % RS, i = w / ROWP, jj = w % ROWP;
         goff[q] = flc;
-        gdst[q] = !in ? -1 : (jj < NX ? (i * NX + jj) * 16 + inst : (jj == NX ? (NK + i) * 16 + inst : -1));
+        gdst[q] = !in ? -1 : (jj < NX ? (i * NX + jj) * TI + inst : (jj == NX ? (NK + i) * TI + inst : -1));
     }
     const double* xptr[NLX];
     size_t xstep[NLX];
@@ -143,7 +149,7 @@ __global__ __launch_bounds__(256) void k_forward_tile(Bufs a, FwdArgs f) {
         const int cc = in ? c : 0;
         if (cc < NX) { xptr[j] = Xc + (size_t)cc * Bp + lb; xstep[j] = (size_t)NX * Bp; xkmax[j] = T - 1; }
         else { xptr[j] = Uc + (size_t)(cc - NX) * Bp + lb; xstep[j] = (size_t)NU * Bp; xkmax[j] = T - 2; }
-        xdst[j] = in ? (NK + NU + cc) * 16 + li : -1;
+        xdst[j] = in ? (NK + NU + cc) * TI + li : -1;
     }
     auto load_step = [&](int k, double* r) {
         const int kg = k < T - 1 ? k : T - 2;
@@ -583,7 +589,7 @@ __global__ __launch_bounds__(64) void k_backward_si(Bufs a) {
 
 template <class S>
 static void launch_v2_kernel(int which, const Bufs& a, int B, int T, hipStream_t st, const FwdArgs& f) {
-    const dim3 gridT(grid_x8((B + 15) / 16)), blockT(256);
+    const dim3 gridT(grid_x8((B + FT_TI - 1) / FT_TI)), blockT(FT_TI * 16);
     switch (which) {
         case KER_FWD_SPEC:
             hipLaunchKernelGGL((k_forward_tile<S, false>), gridT, blockT, 0, st, a, f);
