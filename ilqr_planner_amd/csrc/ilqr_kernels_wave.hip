@@ -58,14 +58,19 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 //   x(1), u(1)   : written to an LDS block by the owning waves, stored by the whole workgroup as full lines once per block.
 //                  (Measured with 16-byte pieces stored by each wave: 0.09 ms of a 0.24 ms launch went into the stores.)
 // Two workgroup barriers per block of 8 steps; nothing else couples the waves.
+// instances per workgroup of k_forward_wg: 16 = eight waves per workgroup and full 128-byte lines per row segment (one workgroup per
+// CU at B = 4096); 8 (64-byte segments, two workgroups per CU) measured 116 us against 110
+#ifndef FW_IW
+#define FW_IW 16
+#endif
 template <int NA>
-__global__ __launch_bounds__(512) void k_forward_wg(Bufs a, FwdArgs f) {
+__global__ __launch_bounds__(FW_IW * 32) void k_forward_wg(Bufs a, FwdArgs f) {
     constexpr int NX = 7, NU = 7, ROWP = kd_rowp(NX), RS = NU * ROWP, NR = NX + NU;
     static_assert(ROWP == 8, "record row = 7 gains + feed-forward");
     constexpr int S = 8, PF = S - 1;     // block length = ring length: slot (step mod 8) is static in the unrolled block
-    constexpr int IW = 16;               // instances per workgroup
+    constexpr int IW = FW_IW, NT = IW * 32;  // instances per workgroup (32 lanes each) and its threads
     constexpr int NSEG = S * NR;         // 112 row segments (lines) per block
-    constexpr int NRND = (NSEG * IW + 511) / 512;  // loader rounds: 4 (the last one half used)
+    constexpr int NRND = (NSEG * IW + NT - 1) / NT;  // loader rounds: 4 (the last one half used)
     __shared__ double sIn[2][NSEG][IW];
     __shared__ double sOut[NSEG][IW];
 
@@ -74,7 +79,7 @@ __global__ __launch_bounds__(512) void k_forward_wg(Bufs a, FwdArgs f) {
     const int b0 = xcd_tile() * IW;
     const int Bp = d.Bp, T = d.T, B = d.B;
     {   // workgroup-uniform exit: every wave looks at all 16 instances
-        const int bi = b0 + (lane & 15);
+        const int bi = b0 + (lane & (IW - 1));
         const bool any = (bi < B) && (a.active[bi < B ? bi : 0] != 0);
         if (__ballot(any ? 1 : 0) == 0ull) return;
     }
@@ -100,7 +105,7 @@ __global__ __launch_bounds__(512) void k_forward_wg(Bufs a, FwdArgs f) {
     int kpi = 0, kp_next = (n_kp > 0) ? d.kp_t[0] : -1;
 
     // ---- cooperative loader / writer: round q of thread tid handles (segment, instance) = ((q*512 + tid) / 16, tid % 16)
-    const int l_inst = tid & 15;
+    const int l_inst = tid % IW;
     const int l_b = (b0 + l_inst < B) ? b0 + l_inst : 0;
     const bool l_ok = (b0 + l_inst < B) && (a.active[l_b] != 0);
     const int l_cur = a.cur[l_b];
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(512) void k_forward_wg(Bufs a, FwdArgs f) {
     size_t l_stride[NRND];
     bool l_valid[NRND];
     UNR for (int q = 0; q < NRND; q++) {
-        const int seg = (q * 512 + tid) >> 4;
+        const int seg = (q * NT + tid) / IW;
         l_valid[q] = seg < NSEG;
         const int sg = l_valid[q] ? seg : 0;
         const int s = sg / NR, row = sg % NR;
@@ -136,12 +141,12 @@ __global__ __launch_bounds__(512) void k_forward_wg(Bufs a, FwdArgs f) {
     };
     auto block_stage = [&](int buf) {
         UNR for (int q = 0; q < NRND; q++)
-            if (l_valid[q]) (&sIn[buf][0][0])[q * 512 + tid] = pre[q];
+            if (l_valid[q]) (&sIn[buf][0][0])[q * NT + tid] = pre[q];
     };
     auto block_store = [&](int k0) {
         UNR for (int q = 0; q < NRND; q++) {
             const int k = k0 + l_s[q];
-            if (l_valid[q] && l_ok && k <= l_kmax[q]) l_dst[q][(size_t)k * l_stride[q]] = (&sOut[0][0])[q * 512 + tid];
+            if (l_valid[q] && l_ok && k <= l_kmax[q]) l_dst[q][(size_t)k * l_stride[q]] = (&sOut[0][0])[q * NT + tid];
         }
     };
 
@@ -483,7 +488,7 @@ static void launch_select(const Bufs& a, int B, hipStream_t st, const FwdArgs& f
 // the rollout itself knows no keypoint function (single-integrator dynamics); the decision kernel is per system kind
 template <class S>
 static void launch_forward_wave_sys(const Bufs& a, int B, hipStream_t st, const FwdArgs& f) {
-    const dim3 grid(grid_x8((B + 15) / 16)), block(512);
+    const dim3 grid(grid_x8((B + FW_IW - 1) / FW_IW)), block(FW_IW * 32);
     if (f.n_alpha <= 1) {
         hipLaunchKernelGGL((k_forward_wg<1>), grid, block, 0, st, a, f);
         launch_select<S, 1>(a, B, st, f);
