@@ -650,9 +650,10 @@ int batchcp_solve(BatchCPState& st, const DevDesc& h, Bufs& bufs, int nx, int nu
                   int nb_iter, int early_stop, hipStream_t stream, std::string& err) {
     (void)nf; (void)nq;
     if (!psi_host || Kw <= 0) { err = "ilqr_solve_batch_cp: null PSI / Kw <= 0"; return 1; }
-    if (Kw > 16) { err = "ilqr_solve_batch_cp: Kw > 16 not supported on the device yet"; return 1; }
+    const bool time_sys = h.kind == 1 || h.kind == 3;
+    if (Kw > 32 || (Kw > 16 && !time_sys)) { err = "ilqr_solve_batch_cp: this path takes Kw <= 16 (Kw <= 32 on the time systems)"; return 1; }
     if (nb_iter < 0) { err = "nb_iter < 0"; return 1; }
-    const int KWP = 16, T = h.T, Bp = h.Bp, nkp = h.n_kp > 0 ? h.n_kp : 1;
+    const int KWP = Kw > 16 ? 32 : 16, T = h.T, Bp = h.Bp, nkp = h.n_kp > 0 ? h.n_kp : 1;
     const int rows = (T - 1) * nu;
     if (st.KWP != KWP || st.nkp != nkp || st.nx != nx || st.Bp != Bp || st.rows != rows) {
         batchcp_free(st);
@@ -685,6 +686,11 @@ int batchcp_solve(BatchCPState& st, const DevDesc& h, Bufs& bufs, int nx, int nu
         return 1;
     }
     static const bool general = std::getenv("ILQR_CP") && !std::strcmp(std::getenv("ILQR_CP"), "general");  // cross-check path
+    if (KWP == 32) {  // wider bases on the time systems: the same kernels with 32 lanes per instance
+        if (h.kind == 3) return run_cp<Sys<3, 1>, 32>(st, h, bufs, nb_iter, early_stop, stream, err);
+        if (h.nd == 1) return run_cp<Sys<1, 1>, 32>(st, h, bufs, nb_iter, early_stop, stream, err);
+        return run_cp<Sys<1, 2>, 32>(st, h, bufs, nb_iter, early_stop, stream, err);
+    }
     if (h.kind == 3) return run_cp<Sys<3, 1>, 16>(st, h, bufs, nb_iter, early_stop, stream, err);
     if (h.kind == 2 && !general) return run_cpl<Sys<2, 1>, 16>(st, h, bufs, psip, nb_iter, early_stop, stream, err);
     if (h.kind == 2) return run_cp<Sys<2, 1>, 16>(st, h, bufs, nb_iter, early_stop, stream, err);

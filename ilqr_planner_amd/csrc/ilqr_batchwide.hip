@@ -865,7 +865,7 @@ int batchwide_solve(BatchWideState& st, const DevDesc& h, Bufs& bufs, int nx, in
     if (h.kind == 0 && h.nd == 1) return run_wl_m<Sys<0, 1>>(st, h, bufs, psi_host, Kw, nb_iter, early_stop, u0_zero, stream, err);
     if (h.kind == 0 && h.nd == 2) return run_wl_m<Sys<0, 2>>(st, h, bufs, psi_host, Kw, nb_iter, early_stop, u0_zero, stream, err);
     if (h.kind == 2) return run_wl_m<Sys<2, 1>>(st, h, bufs, psi_host, Kw, nb_iter, early_stop, u0_zero, stream, err);
-    if (psi_host) { err = "wide-basis batch solve: on time systems only the identity basis (ilqr_solve_batch) is supported for Kw > 16"; return 1; }
+    if (psi_host) { err = "wide-basis batch solve: on time systems only the identity basis (ilqr_solve_batch) is supported for Kw > 32"; return 1; }
     if (h.kind == 1 && h.nd == 1) return run_wt_m<Sys<1, 1>>(st, h, bufs, nb_iter, early_stop, stream, err);
     if (h.kind == 1 && h.nd == 2) return run_wt_m<Sys<1, 2>>(st, h, bufs, nb_iter, early_stop, stream, err);
     if (h.kind == 3) return run_wt_m<Sys<3, 1>>(st, h, bufs, nb_iter, early_stop, stream, err);

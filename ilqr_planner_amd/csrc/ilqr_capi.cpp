@@ -589,7 +589,8 @@ extern "C" int ilqr_solve_batch_cp(ilqr_problem* p, const double* psi, int Kw, i
     std::string err;
     if (ensure_trace(p, nb_iter)) return 1;
     p->last_nb_iter = nb_iter;
-    if (psi && Kw > 16) {  // wide basis: low-rank form of the normal equations (ilqr_batchwide.hip)
+    const bool cp_time = p->desc.kind == ILQR_SYS_POS_ORN_TIME || p->desc.kind == ILQR_SYS_JOINT_TIME;
+    if (psi && Kw > 16 && !(cp_time && Kw <= 32)) {  // wide basis: low-rank form of the normal equations (ilqr_batchwide.hip)
         if (batchwide_solve(p->cpw, p->hdesc, p->bufs, p->dims.n_x, p->dims.n_u, psi, Kw, nb_iter, early_stop, p->u0_zero, c->stream, err)) return fail(c, err);
         return 0;
     }

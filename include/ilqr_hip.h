@@ -172,7 +172,8 @@ int ilqr_solve_recursive(ilqr_problem* p, int nb_iter, int line_search, int earl
 int ilqr_solve_al(ilqr_problem* p, int nb_iter, int lag_update_step, double penalty, double scaling_factor,
                   int line_search, int early_stop);
 /* BatchILQRCP::solve(nb_iter, u0, early_stop, cb) (src/solver/BatchILQRCP.cpp:109-175) with the shared basis
- * PSI ((T-1) n_u x Kw, row-major); u0 = the controls set with ilqr_problem_set_controls. */
+ * PSI ((T-1) n_u x Kw, row-major); u0 = the controls set with ilqr_problem_set_controls.  Kw: any on the constant-dt systems
+ * (Kw > 16 through the low-rank form), up to 32 on the time systems. */
 int ilqr_solve_batch_cp(ilqr_problem* p, const double* psi, int Kw, int nb_iter, int early_stop);
 /* BatchILQR::solve(nb_iter, u0, early_stop, cb) (src/solver/BatchILQR.cpp:110-173): Gauss-Newton on the whole control
  * sequence, i.e. BatchILQRCP with the identity basis (Kw = (T-1) n_u); the identity is never materialised. */

@@ -118,6 +118,35 @@ def test_cp_on_a_sequence_ignores_limits(ctx):
     assert np.all(c_plain > ct[:, 0] + 1e-3)  # the limit terms of the violated joints
 
 
+@pytest.mark.parametrize("cfg_name,T,K", [("C4cp", 30, 3), ("C4t1", 40, 4)])
+def test_cp_time_system_basis_up_to_32_columns(ctx, cfg_name, T, K):
+    """Time systems with 16 < Kw <= 32 (32 lanes per instance in the same kernels): sawtooth x controls + unit step x sqrt(dt) with K
+    pieces each (Kw = 8 K), against the dense restatement; one step to rounding, the trace within the north star's tolerance."""
+    from ilqr_planner_amd import workloads
+
+    B, nb_iter = 10, 5
+    cfg = dict(workloads.config(cfg_name), T=T)
+    desc, inp = workloads.make_batch(ctx, cfg, B=B)
+    psi = psi_of(dict(kind="sawtooth+unitstep_dt", K=K), T, 8)
+    assert 16 < psi.shape[1] <= 32
+    p = workloads.load_batch(ctx, desc, inp, B)
+    p.solve_batch_cp(psi, nb_iter, False)
+    ct, at = p.trace(nb_iter)
+    U = p.U()
+    p.close()
+    bad = 0
+    for i in range(B):
+        s = oracle_system_of_instance(cfg, inp, i)
+        r = orc.solve_batch_cp(s, psi, inp["U0"][i].reshape(-1), nb_iter, False)
+        np.testing.assert_allclose(ct[i][:2], r["trace_cost"][:2], rtol=1e-9)
+        if not np.array_equal(at[i], r["trace_alpha"]):
+            bad += 1
+            continue
+        np.testing.assert_allclose(ct[i], r["trace_cost"], rtol=1e-4)
+        np.testing.assert_allclose(U[i].reshape(-1), r["u"], rtol=0, atol=1e-4 * max(1.0, np.abs(r["u"]).max()))
+    assert bad <= 2
+
+
 def test_cp_errors(ctx):
     from ilqr_planner_amd import workloads
 
@@ -125,5 +154,5 @@ def test_cp_errors(ctx):
     desc, inp = workloads.make_batch(ctx, cfg, B=4)
     p = workloads.load_batch(ctx, desc, inp, 4)
     with pytest.raises(RuntimeError, match="identity basis"):
-        p.solve_batch_cp(np.zeros(((cfg["T"] - 1) * 8, 24)), 1, False)
+        p.solve_batch_cp(np.zeros(((cfg["T"] - 1) * 8, 40)), 1, False)
     p.close()
