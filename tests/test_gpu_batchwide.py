@@ -125,6 +125,33 @@ def test_wide_equals_narrow_path(ctx):
     p.close()
 
 
+@pytest.mark.parametrize("cfg_name,T,B", [("C2", 3, 67), ("C2", 9, 1), ("C4t1", 4, 5), ("C2nd", 5, 33)])
+def test_batch_ilqr_edge_shapes(ctx, cfg_name, T, B):
+    """Shortest horizons (the first keypoint falls on step 0 or 1, where the reference's shifted sensitivity is empty), a single
+    instance, batches that are not a multiple of any lane grouping, early stop on: BatchILQR against the dense restatement."""
+    from ilqr_planner_amd import workloads
+
+    nb_iter = 4
+    cfg = dict(workloads.config(cfg_name), T=T)
+    desc, inp = workloads.make_batch(ctx, cfg, B=B)
+    p = workloads.load_batch(ctx, desc, inp, B)
+    p.solve_batch(nb_iter, True)
+    ct, at = p.trace(nb_iter)
+    iters, U = p.iters(), p.U()
+    p.close()
+    for i in sorted(set([0, B // 2, B - 1])):
+        s = oracle_system_of_instance(cfg, inp, i)
+        r = orc.solve_batch(s, inp["U0"][i].reshape(-1), nb_iter, True)
+        n = r["iters"]
+        assert iters[i] == n
+        np.testing.assert_array_equal(at[i][:n], r["trace_alpha"])
+        tol = 1e-4 if cfg["kind"] in (1, 3) else 1e-6  # time systems amplify the rounding of the two linear solves (see above)
+        np.testing.assert_allclose(ct[i][:min(n, 2)], r["trace_cost"][:2], rtol=1e-9)  # one step: rounding only
+        np.testing.assert_allclose(ct[i][:n], r["trace_cost"], rtol=tol)
+        assert np.all(np.isnan(ct[i][n:]))
+        np.testing.assert_allclose(U[i].reshape(-1), r["u"], rtol=0, atol=tol * max(1.0, np.abs(r["u"]).max()))
+
+
 def test_wide_errors(ctx):
     from ilqr_planner_amd import workloads
 
