@@ -115,3 +115,51 @@ def test_joint_space_system_config1():
     np.testing.assert_allclose(r["X"][24], inp["targets"][0][0][:3], atol=2e-3)
     np.testing.assert_allclose(r["X"][49], inp["targets"][1][0][:3], atol=2e-3)
     assert r["cost"] < 1e-4
+
+
+def test_hybrid_sequence_keypoints():
+    """Hybrid sequences (HYBRID_SYS*.ipynb; no stored trace is reproducible: unseeded targets): the keypoint of the joint-space
+    sub-system inside a PosOrn(Time) problem has f(x) = x, J = I (JointSpacePlannerSys.cpp:77-81), so at its step
+    cost = e'Qe + u'R_sub u (+ limits, once per sub-system), cost_x = -Q e - L'q, cost_xx = Q + L'L with e = target - x -- checked
+    in closed form; the pose keypoint of the same system is untouched by the flag."""
+    rng = np.random.default_rng(8)
+    for timed in (False, True):
+        n = 8 if timed else 7
+        T, dt = 20, (None if timed else 0.1)
+        tgt = rng.uniform(-1, 1, 7)
+        Q = np.diag(rng.uniform(0.5, 2.0, n))
+        Q[0, 1] = Q[1, 0] = 0.3
+        k2 = G["cases"]["POS_ORN_SYS"]["problem"]["keypoints"][1]
+        Qp = np.diag(list(k2["Qdiag"]) + ([0.1] if timed else []))
+        qmax = np.full(7, 0.5)
+        kps = [dict(timestep=9, joint=True, target=tgt, Q=Q, Ru=[1e-3] * n, **(dict(ctime=2.0) if timed else {})),
+               dict(timestep=19, pos=k2["pos"], orn=k2["orn"], Q=Qp, Ru=[1e-4] * n, **(dict(ctime=4.0) if timed else {}))]
+        from tests.helpers import panda_segs
+
+        s = orc.make_system(panda_segs(), orc.SYS_POS_ORN_TIME if timed else orc.SYS_POS_ORN, 1, T, dt, [1e-6] * n, kps, [0.1] * 7, [0.0] * 7,
+                            qmax, -qmax, lim_mult=2)
+        x = rng.uniform(-0.9, 0.9, n)
+        u = rng.uniform(-0.3, 0.3, n)
+        e = np.concatenate([tgt, [2.0]])[:n] - x if timed else tgt - x
+        lim = np.where(x[:7] > 0.5, 0.5 - x[:7], np.where(x[:7] < -0.5, -0.5 - x[:7], 0.0))
+        limf = np.concatenate([lim, np.zeros(n - 7)])
+        want = e @ Q @ e + 1e-3 * (u @ u) + 2 * (limf @ limf)
+        np.testing.assert_allclose(orc.cost(s, x, u, 9), want, rtol=1e-13)
+        np.testing.assert_allclose(orc.cost_x(s, x, 9), -Q @ e - 2 * limf, rtol=1e-13, atol=1e-15)
+        np.testing.assert_allclose(orc.cost_xx(s, x, 9), Q + 2 * np.diag((limf != 0).astype(float)), rtol=1e-13)
+        # the pose keypoint: same values as a system without the joint-space one
+        s2 = orc.make_system(panda_segs(), orc.SYS_POS_ORN_TIME if timed else orc.SYS_POS_ORN, 1, T, dt, [1e-6] * n, kps[1:], [0.1] * 7, [0.0] * 7,
+                             qmax, -qmax, lim_mult=2)
+        assert orc.cost(s, x, u, 19) == orc.cost(s2, x, u, 19)
+        np.testing.assert_array_equal(orc.cost_xx(s, x, 19), orc.cost_xx(s2, x, 19))
+        # Batch-CP on a sequence sees no limit terms (SequentialSystem.cpp:12-18): zero controls keep the state at q0 = 0.1 < 0.5 anyway;
+        # start outside instead
+        s3 = orc.make_system(panda_segs(), orc.SYS_POS_ORN_TIME if timed else orc.SYS_POS_ORN, 1, T, dt, [1e-6] * n, kps, [0.8] * 7, [0.0] * 7,
+                             qmax, -qmax, lim_mult=2)
+        s4 = orc.make_system(panda_segs(), orc.SYS_POS_ORN_TIME if timed else orc.SYS_POS_ORN, 1, T, dt, [1e-6] * n, kps, [0.8] * 7, [0.0] * 7,
+                             qmax, -qmax, lim_mult=1)
+        psi = np.kron(orc.psi("unitstep", T - 1, 2), np.eye(n))
+        u0 = np.tile([0.0] * 7 + ([0.1] if timed else []), T - 1)
+        c_seq = orc.solve_batch_cp(s3, psi, u0, 1, False)["trace_cost"][0]
+        c_plain = orc.solve_batch_cp(s4, psi, u0, 1, False)["trace_cost"][0]
+        assert c_plain > c_seq + 0.1  # 2 keypoint rows x 7 joints x (0.8 - 0.5)^2
