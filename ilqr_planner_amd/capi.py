@@ -66,6 +66,13 @@ class ProblemDesc(C.Structure):
         ("kp_Ru", (C.c_double * MAX_NU) * MAX_KP),
         ("kp_joint", C.c_int * MAX_KP),
         ("limit_multiplicity", C.c_int),
+        ("is_sequence", C.c_int),
+        ("limits2_set", C.c_int),
+        ("penalty2", C.c_double),
+        ("state_max2", C.c_double * (MAX_NX + 1)),
+        ("state_min2", C.c_double * (MAX_NX + 1)),
+        ("limit_weight2", C.c_int * (MAX_NX + 1)),
+        ("limit_multiplicity2", C.c_int),
         ("reg", C.c_double),
         ("alpha_floor", C.c_double),
         ("stop_tol", C.c_double),
@@ -161,7 +168,7 @@ def chain_from_urdf(urdf_text: str, base: str, tip: str, tool_rpy=None, tool_xyz
 
 
 def make_desc(*, kind, nb_deriv, horizon, dt, R_diag, chain, kp_timesteps, kp_Q, limits=None, kp_dist=None, kp_frames=None, kp_Ru=None,
-              limit_multiplicity=1, kp_joint=None) -> ProblemDesc:
+              limit_multiplicity=1, kp_joint=None, limits2=None) -> ProblemDesc:
     """chain: dict(seg_joint, seg_xyz, seg_R, seg_axis, dof); limits: dict(state_max, state_min, limit_weight, penalty) or None."""
     L = load()
     d = ProblemDesc()
@@ -201,6 +208,13 @@ def make_desc(*, kind, nb_deriv, horizon, dt, R_diag, chain, kp_timesteps, kp_Q,
             for b in range(nqk):
                 d.kp_Q[k][a * nqk + b] = Q[a, b]
     d.limit_multiplicity = int(limit_multiplicity)  # SequentialSystem: number of sub-systems
+    if limits2 is not None:  # second group of sub-systems with other bounds: dict(state_max, state_min, limit_weight[, penalty, multiplicity])
+        d.is_sequence, d.limits2_set, d.penalty2 = 1, 1, float(limits2.get("penalty", 1.0))
+        d.limit_multiplicity2 = int(limits2.get("multiplicity", 1))
+        for i in range(len(limits2["state_max"])):
+            d.state_max2[i] = float(limits2["state_max"][i])
+            d.state_min2[i] = float(limits2["state_min"][i])
+            d.limit_weight2[i] = int(limits2["limit_weight"][i])
     for k, fr in enumerate(kp_frames or []):  # 4x4 pose of the object frame of keypoint k's sub-system (TransformedSimulationInterface) or None
         if fr is not None:
             Tm = _f64(fr, (4, 4))

@@ -958,22 +958,47 @@ void SequentialSystem::lower(ilqr_problem_desc* d) const {
     const bool hybrid = !is_joint(d->kind);
     if ((int)Rdiag.size() != nb_ctrl_var_) throw std::runtime_error("[System] RtDiag must have nb_ctrl_var entries");
     for (int i = 0; i < nb_ctrl_var_; i++) d->R_diag[i] = Rdiag[i];  // l_u = R u, l_uu = R use the sequential system's own Rt
-    int n_lim = 0;
+    // limit terms: every sub-system adds its own (SequentialSystem.cpp:143-165).  Sub-systems with the same bounds form a group that
+    // counts with its multiplicity; a second group with other bounds goes to the descriptor's second limit set (generic kernels).
+    int n_lim = 0, n_lim2 = 0;
+    bool have2 = false;
+    auto same_limits = [&](const ilqr_problem_desc& a, const double* smax, const double* smin, const int* lw, double pen) {
+        for (int j = 0; j < nb_state_var_; j++)
+            if (a.state_max[j] != smax[j] || a.state_min[j] != smin[j] || a.limit_weight[j] != lw[j]) return false;
+        return a.penalty == pen;
+    };
+    bool first_set = false;
     for (size_t i = 0; i < subs.size(); i++) {
         const auto& a = subs[i];
         const bool mixed = a.kind != d->kind;
         if (mixed && !(hybrid && is_joint(a.kind) && is_time(a.kind) == is_time(d->kind) && d->nb_deriv == 1 && a.dof == d->dof))
             throw std::runtime_error("[ilqr_hip] these sub-system kinds cannot be lowered together (joint-space next to PosOrn needs nbDeriv = 1 and 7 joints)");
         if (a.dt != d->dt) throw std::runtime_error("[ilqr_hip] sub-systems of different kinds / dt cannot be lowered");
-        if (a.limits_set != d->limits_set) throw std::runtime_error("[ilqr_hip] sub-systems with and without limits cannot be lowered together");
-        if (a.limits_set) {
+        if (!a.limits_set) continue;
+        if (!first_set) {  // the first limited sub-system defines the first set (the base descriptor may be another sub-system's)
+            first_set = true;
+            d->limits_set = 1;
+            d->penalty = a.penalty;
+            for (int j = 0; j < nb_state_var_; j++) { d->state_max[j] = a.state_max[j]; d->state_min[j] = a.state_min[j]; d->limit_weight[j] = a.limit_weight[j]; }
+            n_lim = 1;
+        } else if (same_limits(a, d->state_max, d->state_min, d->limit_weight, d->penalty)) {
             n_lim++;
-            for (int j = 0; j < nb_state_var_; j++)
-                if (a.state_max[j] != d->state_max[j] || a.state_min[j] != d->state_min[j] || a.limit_weight[j] != d->limit_weight[j] || a.penalty != d->penalty)
-                    throw std::runtime_error("[ilqr_hip] sub-systems with different limits cannot be lowered");
+        } else if (!have2) {
+            have2 = true;
+            d->limits2_set = 1;
+            d->penalty2 = a.penalty;
+            for (int j = 0; j < nb_state_var_; j++) { d->state_max2[j] = a.state_max[j]; d->state_min2[j] = a.state_min[j]; d->limit_weight2[j] = a.limit_weight[j]; }
+            n_lim2 = 1;
+        } else if (same_limits(a, d->state_max2, d->state_min2, d->limit_weight2, d->penalty2)) {
+            n_lim2++;
+        } else {
+            throw std::runtime_error("[ilqr_hip] sub-systems with more than two different sets of limits cannot be lowered");
         }
     }
+    if (!first_set) d->limits_set = 0;
     d->limit_multiplicity = n_lim > 1 ? n_lim : 1;
+    d->limit_multiplicity2 = n_lim2 > 1 ? n_lim2 : 1;
+    d->is_sequence = 1;
     // merge the keypoints by timestep
     struct Src { int sys, k; };
     std::vector<Src> order;

@@ -247,7 +247,14 @@ static int lower_desc(ilqr_ctx* c, const ilqr_problem_desc& d, int B, int Bp, De
         h.limits_set = d.limits_set;
         h.penalty = d.penalty * mult;
         h.pen_xx = d.penalty * d.penalty * mult;
-        h.batch_limits = d.limit_multiplicity > 1 ? 0 : 1;
+        h.batch_limits = (d.limit_multiplicity > 1 || d.is_sequence) ? 0 : 1;
+        h.lim2 = d.limits2_set ? 1 : 0;
+        if (d.limits2_set) {
+            const double mult2 = d.limit_multiplicity2 > 1 ? (double)d.limit_multiplicity2 : 1.0;
+            h.penalty2 = d.penalty2 * mult2;
+            h.pen_xx2 = d.penalty2 * d.penalty2 * mult2;
+            for (int i = 0; i < dm.n_x; i++) { h.smax2[i] = d.state_max2[i]; h.smin2[i] = d.state_min2[i]; h.lw2[i] = d.limit_weight2[i]; }
+        }
     }
     for (int i = 0; i < dm.n_x; i++) { h.smax[i] = d.state_max[i]; h.smin[i] = d.state_min[i]; h.lw[i] = d.limit_weight[i]; }
     if (d.n_kp < 0 || d.n_kp > ILQR_MAX_KP) return fail(c, "bad n_kp");
@@ -497,7 +504,7 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
     // number of step sizes the do/while of ILQRRecursive.cpp:101-155 can reach: 1, 1/2, ... until alpha <= alpha_floor
     int n_alpha = 1;
     if (line_search) { double al_ = 1.0; while (al_ > p->desc.alpha_floor && n_alpha < 64) { al_ *= 0.5; n_alpha++; } }
-    const int path = path_choice();
+    const int path = p->desc.limits2_set ? 1 : path_choice();  // a second limit set exists in the generic kernels only
     const bool fwd_tile = (path != 1) && n_alpha <= 16;
     const char* fwd_env = std::getenv("ILQR_FWD");
     const bool fwd_rows = fwd_tile && forward_rows_supported(kind, nd, n_alpha) && !(fwd_env && !std::strcmp(fwd_env, "tile"));

@@ -51,6 +51,9 @@ struct DevDesc {
     double kp_Ru[MAX_KP][MAX_NU];
     int kp_joint[MAX_KP];              // Angular(Time)Keypoint of a joint-space sub-system inside a PosOrn(Time) system (hybrid SequentialSystem,
                                        // nb_deriv = 1): residual target - x, J = I, precision n_x x n_x (leading dimension n_x)
+    int lim2;                          // second limit set (sub-systems of a sequence with other bounds); generic kernels only
+    double smax2[MAX_NX + 1], smin2[MAX_NX + 1], penalty2, pen_xx2;  // penalty2 = penalty x multiplicity, pen_xx2 = penalty^2 x multiplicity
+    int lw2[MAX_NX + 1];
     int batch_limits;                  // 0: the batch solvers see no limit terms (sequence of sub-systems: SequentialSystem does not override
                                        // fpBatch, and the sequence object itself has no limits); 1: plain system
     double pen_xx;                     // penalty^2 x limit multiplicity (l_xx of a violated limit); `penalty` holds penalty x multiplicity

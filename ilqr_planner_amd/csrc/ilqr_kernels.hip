@@ -85,6 +85,7 @@ __global__ __launch_bounds__(64) void k_backward(Bufs a) {
         // allocator into spilling SGPRs to VGPR lanes
         if (iskp) stage_derivs_call<S>(&d, &a, b, kpi, x, &P[0][0], p);
         else stage_derivs<S>(d, a, b, x, -1, P, p);
+        if (d.lim2) lim2_derivs<S>(d, x, P, p);
         if (iskp) kpi--;
     }
     for (int k = T - 2; k >= 0; k--) {
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(64) void k_backward(Bufs a) {
             const bool iskp = (kpi >= 0 && d.kp_t[kpi] == k);
             if (iskp) stage_derivs_call<S>(&d, &a, b, kpi, x, &lxx[0][0], lx);
             else stage_derivs<S>(d, a, b, x, -1, lxx, lx);
+            if (d.lim2) lim2_derivs<S>(d, x, lxx, lx);
             if (iskp) kpi--;
         }
         // BtP = B^T P (NU x NX), AtP = A^T P (NX x NX)

@@ -175,6 +175,34 @@ ILQR_DEV void inverse_lu(double (*M)[N], double (*Inv)[N]) {
 
 // ------------------------------------------------------------------------------------------------ rollout pieces
 
+// Second limit set of a sequence whose sub-systems have different bounds (ilqr_problem_desc::limits2_set): the limit terms of that
+// group of sub-systems, same form as the first set (inspectJointLimit, System.cpp:121-142).  Only the generic kernels call these.
+template <class S>
+ILQR_DEV double lim2_cost(const DevDesc& d, const double* x) {
+    double a = 0;
+    UNR for (int i = 0; i < S::NX; i++) {
+        if (d.lw2[i] != 0) {
+            double qv = 0, L = 0;
+            if (x[i] > d.smax2[i]) { qv = d.smax2[i] - x[i]; L = d.penalty2; }
+            else if (x[i] < d.smin2[i]) { qv = d.smin2[i] - x[i]; L = d.penalty2; }
+            a += qv * L * qv;
+        }
+    }
+    return a;
+}
+template <class S>
+ILQR_DEV void lim2_derivs(const DevDesc& d, const double* x, double (*lxx)[S::NX], double* lx) {
+    UNR for (int i = 0; i < S::NX; i++) {
+        if (d.lw2[i] != 0) {
+            double qv = 0, L = 0;
+            if (x[i] > d.smax2[i]) { qv = d.smax2[i] - x[i]; L = d.penalty2; }
+            else if (x[i] < d.smin2[i]) { qv = d.smin2[i] - x[i]; L = d.penalty2; }
+            lx[i] += -L * qv;
+            lxx[i][i] += (L != 0.0) ? d.pen_xx2 : 0.0;
+        }
+    }
+}
+
 // stage cost l(x,u,k) (System::cost): task part only at keypoint steps, limits always
 template <class S>
 ILQR_DEV double stage_cost(const DevDesc& d, const Bufs& a, int b, int kpi, const double* x, const double* u) {
@@ -186,6 +214,7 @@ ILQR_DEV double stage_cost(const DevDesc& d, const Bufs& a, int b, int kpi, cons
         c += kp_cost<S>(d, kpi, tg, x, u);
     }
     if (d.limits_set) c += limit_cost<S>(d, x);
+    if (d.lim2) c += lim2_cost<S>(d, x);
     return c;
 }
 

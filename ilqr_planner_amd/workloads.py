@@ -61,6 +61,10 @@ def config(name: str):
         # sub-system, own control penalty 1e-3) followed by a pose goal of a PosOrn(Time)PlannerSys sub-system, limits counted twice
         "C2h": dict(kind=capi.SYS_POS_ORN, nb_deriv=1, T=100, dt=0.05, B=256, seed=12, Qdiag=[[1] * 7, P], solver="recursive", nb_iter=12, hybrid=True,
                     psi=dict(kind="unitstep", K=2)),
+        # the same with two limit sets, as when the sub-systems of a sequence are given different bounds (HYBRID_SYS_TIME.ipynb does that):
+        # the second sub-system's bounds are 0.3 rad inside the first one's
+        "C2hl": dict(kind=capi.SYS_POS_ORN, nb_deriv=1, T=100, dt=0.05, B=128, seed=14, Qdiag=[[1] * 7, P], solver="recursive", nb_iter=12, hybrid=True,
+                     limits2=True),
         "C4h": dict(kind=capi.SYS_POS_ORN_TIME, nb_deriv=1, T=100, dt=None, B=128, seed=13, Qdiag=[[1] * 7 + [0], P + [.1]], ctimes=[2.5, 5.0],
                     solver="recursive", nb_iter=12, hybrid=True),
         "C4cp": dict(kind=capi.SYS_POS_ORN_TIME, nb_deriv=2, T=50, dt=None, B=64, seed=5, Qdiag=[P + V + [.1], P + V + [.1]],
@@ -97,7 +101,8 @@ def make_batch(ctx: capi.Context, cfg: dict, B: int | None = None, seed: int | N
     desc = capi.make_desc(kind=kind, nb_deriv=nd, horizon=T, dt=cfg["dt"], R_diag=[1e-5] * nu, chain=chain, kp_timesteps=kp_t,
                           kp_Q=[np.diag(q) for q in cfg["Qdiag"]], limits=dict(state_max=smax, state_min=smin, limit_weight=w, penalty=1.0),
                           kp_dist=cfg.get("kp_dist"), kp_joint=[1, 0] if hyb else None, kp_Ru=[[1e-3] * nu, [1e-5] * nu] if hyb else None,
-                          limit_multiplicity=2 if hyb else 1)
+                          limit_multiplicity=(1 if cfg.get("limits2") else 2) if hyb else 1,
+                          limits2=dict(state_max=smax - 0.3 * (w != 0), state_min=smin + 0.3 * (w != 0), limit_weight=w, penalty=1.0) if cfg.get("limits2") else None)
     q0 = np.clip(Q0_TUT[None, :] + rng.uniform(-0.3, 0.3, (B, dof)), lo, up)
     targets = []
     for i in range(2):

@@ -110,6 +110,17 @@ typedef struct {
      * (src/system/JointSpacePlannerSys.cpp:77-81), precision n_x x n_x in kp_Q[k] with leading dimension n_x. */
     int kp_joint[ILQR_MAX_KP];
     int limit_multiplicity;
+    /* is_sequence: the problem is a sys::SequentialSystem (set by its lowering; limit_multiplicity > 1 implies it): the batch solvers
+     * then apply no limit terms.  limits2_set: a second group of sub-systems whose bounds differ from the first group's
+     * (HYBRID_SYS_TIME.ipynb gives its two sub-systems (qMax, qMin) and (qMax, -qMax)); every group adds its own limit terms,
+     * limit_multiplicity2 times.  Problems with a second group run on the generic one-lane-per-instance kernels. */
+    int is_sequence;
+    int limits2_set;
+    double penalty2;
+    double state_max2[ILQR_MAX_NX + 1];
+    double state_min2[ILQR_MAX_NX + 1];
+    int limit_weight2[ILQR_MAX_NX + 1];
+    int limit_multiplicity2;
     double reg;          /* 1e-6 */
     double alpha_floor;  /* 1e-3 */
     double stop_tol;     /* 1e-3 */

@@ -441,6 +441,18 @@ static void limits(const orc_system* s, const double* x, double* Ld, double* q) 
     }
 }
 
+/* the second group of sub-systems of a sequence: same inspectJointLimit on its own bounds (penalty 1 like every limited System) */
+static void limits2(const orc_system* s, const double* x, double* Ld, double* q) {
+    for (int i = 0; i < s->n_x; i++) { Ld[i] = 0; q[i] = 0; }
+    if (!s->limits2_set) return;
+    for (int i = 0; i < s->n_x; i++) {
+        if (s->limit_weight2[i] != 0) {
+            if (x[i] > s->state_max2[i]) { q[i] = s->state_max2[i] - x[i]; Ld[i] = s->penalty; }
+            else if (x[i] < s->state_min2[i]) { q[i] = s->state_min2[i] - x[i]; Ld[i] = s->penalty; }
+        }
+    }
+}
+
 /* System::cost, System.cpp:213-234 (control cost only at keypoint steps: quirk D-2) */
 double orc_cost(const orc_system* s, const double* x, const double* u, int k) {
     double c = 0;
@@ -461,6 +473,12 @@ double orc_cost(const orc_system* s, const double* x, const double* u, int k) {
         limits(s, x, Ld, q);
         for (int i = 0; i < s->n_x; i++) a += q[i] * Ld[i] * q[i];
         c += a * (s->lim_mult > 1 ? s->lim_mult : 1);
+    }
+    if (s->limits2_set) {
+        double Ld[ORC_MAX_NX], q[ORC_MAX_NX], a = 0;
+        limits2(s, x, Ld, q);
+        for (int i = 0; i < s->n_x; i++) a += q[i] * Ld[i] * q[i];
+        c += a * (s->lim2_mult > 1 ? s->lim2_mult : 1);
     }
     return c;
 }
@@ -487,6 +505,11 @@ void orc_cost_x(const orc_system* s, const double* x, int k, double* lx) {
         limits(s, x, Ld, q);
         for (int i = 0; i < nx; i++) lx[i] += -Ld[i] * q[i] * (s->lim_mult > 1 ? s->lim_mult : 1);
     }
+    if (s->limits2_set) {
+        double Ld[ORC_MAX_NX], q[ORC_MAX_NX];
+        limits2(s, x, Ld, q);
+        for (int i = 0; i < nx; i++) lx[i] += -Ld[i] * q[i] * (s->lim2_mult > 1 ? s->lim2_mult : 1);
+    }
 }
 
 /* System::cost_xx, System.cpp:286-308:  J^T Q J + L^T L */
@@ -506,6 +529,11 @@ void orc_cost_xx(const orc_system* s, const double* x, int k, double* lxx) {
         double Ld[ORC_MAX_NX], q[ORC_MAX_NX];
         limits(s, x, Ld, q);
         for (int i = 0; i < nx; i++) lxx[i * nx + i] += Ld[i] * Ld[i] * (s->lim_mult > 1 ? s->lim_mult : 1);
+    }
+    if (s->limits2_set) {
+        double Ld[ORC_MAX_NX], q[ORC_MAX_NX];
+        limits2(s, x, Ld, q);
+        for (int i = 0; i < nx; i++) lxx[i * nx + i] += Ld[i] * Ld[i] * (s->lim2_mult > 1 ? s->lim2_mult : 1);
     }
 }
 
@@ -803,7 +831,7 @@ static void fp_batch_run(const orc_system* s, const double* u, fp_batch* f) {
         /* a SequentialSystem does not override fpBatch / forwardPassWithLimits (SequentialSystem.h:31-41): they run on the sequence
          * object itself, which is built by the constructor WITHOUT limits (SequentialSystem.cpp:12-18: limits_set_ = false), so the batch
          * solvers see no limit terms at all -- unlike ILQRRecursive, whose cost, cost_x, cost_xx are the sums over the sub-systems */
-        if (!(s->lim_mult > 1)) limits(s, x, f->L + (size_t)(i + 1) * nx, f->qL + (size_t)(i + 1) * nx);
+        if (!(s->lim_mult > 1 || s->sequence)) limits(s, x, f->L + (size_t)(i + 1) * nx, f->qL + (size_t)(i + 1) * nx);
         {   /* a keypoint whose system works in an object frame (TransformedSimulationInterface): f(x) and J in that frame */
             const orc_keypoint* kf = find_kp(s, i + 1);
             if (kf && (kf->has_frame || kf->joint)) fx_jac_frame(s, kf, xn, f->fX + (size_t)(i + 1) * nf, f->J + (size_t)(i + 1) * nq * nx);

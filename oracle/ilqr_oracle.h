@@ -89,6 +89,11 @@ typedef struct {
     orc_keypoint kp[ORC_MAX_KP];
     /* derived by orc_system_finalize() (localInit, PosOrnPlannerSys.cpp:54-78 / PosOrnTimePlannerSys.cpp:50-83) */
     int dof, n_x, n_u, n_f, n_Q;
+    /* SequentialSystem whose sub-systems have different bounds (HYBRID_SYS_TIME.ipynb: (qMax, qMin) and (qMax, -qMax)): the second
+     * group's limits; cost, cost_x, cost_xx add them lim2_mult times (SequentialSystem.cpp:143-165 sums the sub-systems) */
+    int limits2_set, lim2_mult, sequence;  /* sequence: the batch solvers see no limit terms even when lim_mult is 1 */
+    double state_max2[ORC_MAX_NX], state_min2[ORC_MAX_NX];
+    int limit_weight2[ORC_MAX_NX];
 } orc_system;
 
 void orc_system_finalize(orc_system* s);

@@ -80,6 +80,12 @@ class System(C.Structure):
         ("n_u", C.c_int),
         ("n_f", C.c_int),
         ("n_Q", C.c_int),
+        ("limits2_set", C.c_int),
+        ("lim2_mult", C.c_int),
+        ("sequence", C.c_int),
+        ("state_max2", C.c_double * MAX_NX),
+        ("state_min2", C.c_double * MAX_NX),
+        ("limit_weight2", C.c_int * MAX_NX),
     ]
 
 
@@ -231,7 +237,8 @@ def make_chain(segs) -> Chain:
 # ----------------------------------------------------------------------------- problem construction
 
 
-def make_system(segs, kind, nb_deriv, T, dt, R_diag, keypoints, q0, dq0=None, qMax=None, qMin=None, dqMax=None, dqMin=None, lim_mult=1) -> System:
+def make_system(segs, kind, nb_deriv, T, dt, R_diag, keypoints, q0, dq0=None, qMax=None, qMin=None, dqMax=None, dqMin=None, lim_mult=1,
+                limits2=None) -> System:
     """Mirror of the System constructors (reference src/system/System.cpp:19-75) + localInit.
     keypoints: list of dict(timestep,pos,orn,Q[,dpos,dorn][,ctime]); sorted by timestep here (System.cpp:82)."""
     s = System()
@@ -265,6 +272,10 @@ def make_system(segs, kind, nb_deriv, T, dt, R_diag, keypoints, q0, dq0=None, qM
         # time systems append a zero-weight entry (PosOrnTimePlannerSys.cpp:72-83): arrays are zero-initialised
     else:
         s.limits_set, s.penalty = 0, 0.0
+    if limits2 is not None:  # second group of sub-systems of a sequence: dict(qMax, qMin[, mult]) (nb_deriv = 1)
+        s.limits2_set, s.sequence, s.lim2_mult = 1, 1, int(limits2.get("mult", 1))
+        for i in range(dof):
+            s.state_max2[i], s.state_min2[i], s.limit_weight2[i] = limits2["qMax"][i], limits2["qMin"][i], 1
     kps = sorted(keypoints, key=lambda k: k["timestep"])
     s.n_kp = len(kps)
     nq = s.n_Q

@@ -418,8 +418,8 @@ def test_hybrid_sys_time_tutorial(capsys):
     dof, nb_ctrl_var, horizon = 7, 8, 500
     q0, dq0 = g["q0"], [0] * dof
     qMax = np.array([2.8973, 1.7628, 2.8973, -0.0698, 2.8973, 3.7525, 2.8973])
-    qMin = np.array([-2.8973, -1.7628, -2.8973, -3.0718, -2.8973, -0.0175, -2.8973])  # the notebook gives sys1 (qMax, qMin) and sys2
-    # (qMax, -qMax), an inverted bound on joint 4; both sub-systems get (qMax, qMin) here: sub-systems with different limits do not lower
+    qMin = np.array([-2.8973, -1.7628, -2.8973, -3.0718, -2.8973, -0.0175, -2.8973])  # sys1 gets (qMax, qMin), sys2 (qMax, -qMax) as in the
+    # notebook: two different limit sets (and, with qMax[3] < 0, an inverted bound on joint 4 in the second one)
     rbt = KDLRobot(URDF, "panda_link0", "panda_tip", q0, dq0)
     target_1 = np.random.default_rng(22).uniform(-1.5, 1.5, dof)
     Q1 = np.identity(dof + 1)
@@ -429,12 +429,13 @@ def test_hybrid_sys_time_tutorial(capsys):
     k1 = g["keypoints"][0]
     Q2 = np.diag(list(k1["Qdiag"]) + [0])
     kp2 = SpacetimeKeypoint(np.array(k1["pos"]), np.array(k1["orn"]), Q2, 5, horizon - 1)
-    sys2 = PosOrnTimePlannerSys(rbt, [kp2], (np.ones(nb_ctrl_var) * 1e-5).tolist(), qMax, qMin, horizon, 1)
+    sys2 = PosOrnTimePlannerSys(rbt, [kp2], (np.ones(nb_ctrl_var) * 1e-5).tolist(), qMax, -qMax, horizon, 1)
     sys_ = SequentialSystem(rbt, [sys1, sys2], [1e-5] * nb_ctrl_var, horizon, 1)
     assert (sys_.get_nb_state_var(), sys_.get_nb_ctrl_var(), sys_.get_nb_target_var(), sys_.get_horizon()) == (8, 8, 16, 500)
     so = orc.make_system(panda_segs(), orc.SYS_POS_ORN_TIME, 1, horizon, None, [1e-5] * 8, [
         dict(timestep=horizon // 2 - 1, joint=True, target=target_1, ctime=2.5, Q=Q1, Ru=[1e-5] * 8),
-        dict(timestep=horizon - 1, pos=k1["pos"], orn=k1["orn"], ctime=5, Q=Q2, Ru=[1e-5] * 8)], q0, dq0, qMax, qMin, lim_mult=2)
+        dict(timestep=horizon - 1, pos=k1["pos"], orn=k1["orn"], ctime=5, Q=Q2, Ru=[1e-5] * 8)], q0, dq0, qMax, qMin, lim_mult=1,
+        limits2=dict(qMax=qMax, qMin=-qMax))
     u0 = np.tile(np.array([0] * (nb_ctrl_var - 1) + [0.1]), horizon - 1)
     PSI = np.kron(primitives.build_psi_unitstep(horizon - 1, 2), np.identity(nb_ctrl_var))
     cb = PythonCallbackMessage()
