@@ -42,6 +42,11 @@ def config(name: str):
         # C3: AL-iLQR with the tutorial's single row q_6 <= 2.0 (penalty .25, scaling 1.1, update every 5)
         "C3": dict(kind=capi.SYS_POS_ORN, nb_deriv=1, T=200, dt=0.05, B=4096, seed=2, Qdiag=[P, P], solver="al", nb_iter=20,
                    al=dict(row=5, bound=2.0, penalty=0.25, scaling=1.1, lag=5)),
+        # AL-iLQR on the other system shapes (same single row q_6 <= 2.0): 2nd order, time state
+        "C2ndal": dict(kind=capi.SYS_POS_ORN, nb_deriv=2, T=100, dt=0.05, B=64, seed=15, Qdiag=[P + [1, 1, 1, 0, 0, 0], P + V], solver="al", nb_iter=10,
+                       al=dict(row=5, bound=2.0, penalty=0.25, scaling=1.1, lag=5)),
+        "C4t1al": dict(kind=capi.SYS_POS_ORN_TIME, nb_deriv=1, T=100, dt=None, B=64, seed=16, Qdiag=[P + [0], P + [.1]], ctimes=[2.0, 5.0], solver="al",
+                       nb_iter=10, al=dict(row=5, bound=2.0, penalty=0.25, scaling=1.1, lag=5)),
         "C3r": dict(kind=capi.SYS_POS_ORN, nb_deriv=1, T=200, dt=0.05, B=4096, seed=2, Qdiag=[P, P], solver="recursive", nb_iter=20),
         # PosOrnKeypointDistFunct: dead zones of 5 cm / 0.1 rad at the via point, 1 cm / mixed thresholds at the goal
         "C3d": dict(kind=capi.SYS_POS_ORN, nb_deriv=1, T=100, dt=0.05, B=256, seed=8, Qdiag=[P, P], solver="recursive", nb_iter=15,
