@@ -47,6 +47,10 @@ def config(name: str):
                        al=dict(row=5, bound=2.0, penalty=0.25, scaling=1.1, lag=5)),
         "C4t1al": dict(kind=capi.SYS_POS_ORN_TIME, nb_deriv=1, T=100, dt=None, B=64, seed=16, Qdiag=[P + [0], P + [.1]], ctimes=[2.0, 5.0], solver="al",
                        nb_iter=10, al=dict(row=5, bound=2.0, penalty=0.25, scaling=1.1, lag=5)),
+        "C1jal": dict(kind=capi.SYS_JOINT, nb_deriv=1, T=100, dt=0.1, B=64, seed=17, dof=7, Qdiag=[[1] * 7, [1, .5, 1, .5, 1, .5, 1]], solver="al", nb_iter=8,
+                      al=dict(row=5, bound=1.0, penalty=0.25, scaling=1.1, lag=3)),
+        "C1tal": dict(kind=capi.SYS_JOINT_TIME, nb_deriv=1, T=60, dt=None, B=64, seed=18, dof=7, Qdiag=[[1] * 7 + [0], [1] * 7 + [.1]], ctimes=[2.0, 4.0],
+                      solver="al", nb_iter=8, al=dict(row=5, bound=0.5, penalty=0.25, scaling=1.1, lag=3)),
         "C3r": dict(kind=capi.SYS_POS_ORN, nb_deriv=1, T=200, dt=0.05, B=4096, seed=2, Qdiag=[P, P], solver="recursive", nb_iter=20),
         # PosOrnKeypointDistFunct: dead zones of 5 cm / 0.1 rad at the via point, 1 cm / mixed thresholds at the goal
         "C3d": dict(kind=capi.SYS_POS_ORN, nb_deriv=1, T=100, dt=0.05, B=256, seed=8, Qdiag=[P, P], solver="recursive", nb_iter=15,
@@ -167,6 +171,11 @@ def _make_joint_batch(cfg, B, seed, limits):
     if tm:
         U0[:, :, -1] = 0.01  # as the time-system tutorials start (POS_ORN_TIME_SYS.ipynb cell 8)
     inp = dict(q0=q0, dq0=np.zeros((B, D)), targets=targets, U0=U0, kp_t=kp_t, dof=dofu, limits=dict(state_max=smax, state_min=smin, limit_weight=w))
+    if cfg.get("al"):  # one inequality row on a joint (7-joint problems only: the constraint rows are not padded)
+        al = cfg["al"]
+        A = np.zeros((1, 2 * n))
+        A[0, al["row"]] = 1.0
+        inp.update(A=A, b=np.array([al["bound"]]), lambda0=np.full((B, T - 1, 1), al["bound"]))
     return desc, inp
 
 
