@@ -227,6 +227,48 @@ def test_fk_batch_vs_oracle(ctx):
     np.testing.assert_allclose(quat0[0], g["quat_from_notebook"], atol=5e-9)
 
 
+@pytest.mark.parametrize("per_step,with_control_row", [(False, True), (True, False), (True, True)])
+def test_al_constraint_shapes(ctx, per_step, with_control_row):
+    """AL-iLQR beyond the tutorial's single shared state row: several rows, bounds that change with the timestep (one constraint set
+    per step, AL-ILQR.h:20-36), rows on the controls (these leave the closed-form sweep for the generic one).  Final cost against the
+    oracle under the same sensitivity rule as the random batches."""
+    from ilqr_planner_amd import workloads
+
+    cfg = dict(workloads.config("C3"), T=60)
+    B, nb_iter, T = 24, 10, 60
+    desc, inp = workloads.make_batch(ctx, cfg, B=B)
+    m = 3 if with_control_row else 2
+    A = np.zeros((m, 14))
+    A[0, 5] = 1.0   # q_6 <= 2.0
+    A[1, 1] = -1.0  # -q_2 <= 1.2
+    if with_control_row:
+        A[2, 7 + 3] = 1.0  # dq_4 <= 0.6
+    b = np.array([2.0, 1.2, 0.6][:m])
+    if per_step:
+        A = np.tile(A, (T - 1, 1, 1))
+        b = np.tile(b, (T - 1, 1)) + 0.002 * np.arange(T - 1)[:, None]
+    lam0 = np.tile(b if per_step else np.tile(b, (T - 1, 1)), (B, 1, 1))
+    p = workloads.load_batch(ctx, desc, inp, B)
+    p.set_constraints(A, b, lam0)
+    al = cfg["al"]
+    p.solve_al(nb_iter, al["lag"], al["penalty"], al["scaling"], True, True)
+    cost, at = p.cost(), p.trace(nb_iter)[1]
+    p.close()
+    from tests.helpers import oracle_system_of_instance
+
+    rel, same = [], 0
+    for i in range(B):
+        s = oracle_system_of_instance(cfg, inp, i)
+        r = orc.solve_al(s, A, b, lam0[i], inp["U0"][i].reshape(-1), nb_iter, al["lag"], al["penalty"], al["scaling"], True, True)
+        if not (np.isfinite(r["cost"]) and np.isfinite(cost[i])):
+            continue
+        rel.append(abs(cost[i] - r["cost"]) / max(abs(r["cost"]), 1e-12))
+        same += int(np.array_equal(at[i][: r["iters"]], r["trace_alpha"]))
+    rel = np.asarray(rel)
+    assert len(rel) >= B // 2 and np.median(rel) <= 1e-6, f"median rel err {np.median(rel):.2e}"
+    assert (rel <= COST_RTOL).mean() >= 0.8, f"{(rel > COST_RTOL).sum()} of {len(rel)} outside 1e-4 (max {rel.max():.2e})"
+
+
 def test_empty_and_ragged_inputs(ctx):
     """nb_iter = 0 (rollout only), batch not a multiple of the wave size, early stop off, line search off."""
     from ilqr_planner_amd import workloads
