@@ -254,7 +254,7 @@ def main():
             "nonfinite_frac": float(np.mean((status & 1) != 0)),
             "roofline": roof,
         }
-        if not args.no_cpu_baseline and cfg["solver"] != "batch_cp":
+        if not args.no_cpu_baseline and world == 1 and cfg["solver"] != "batch_cp":  # the CPU baseline belongs to the N = 1 line only
             cb, ccost = cpu_baseline(cfg, inp, nb_iter)
             out["cpu_baseline"] = cb
             ref = np.array(ccost)
