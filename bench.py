@@ -257,6 +257,10 @@ def main():
         if not args.no_cpu_baseline and world == 1 and cfg["solver"] != "batch_cp":  # the CPU baseline belongs to the N = 1 line only
             cb, ccost = cpu_baseline(cfg, inp, nb_iter)
             out["cpu_baseline"] = cb
+            # the reference's own published timing, for orientation only: not measured here, other hardware, other horizon
+            cb["reference_published_not_measured_here"] = dict(
+                value=745, unit="iterations/s", what="ILQRRecursive, PosOrn 1st order, T=100, one instance, one thread, unknown CPU",
+                source="pylqr_planner/Tutorials/POS_ORN_SYS.ipynb:342-348 (time= fields of the stored output; BASELINE.md)")
             ref = np.array(ccost)
             rel = np.abs(cost[: len(ref)] - ref) / np.maximum(np.abs(ref), 1e-12)
             out["final_cost_rel_err_vs_oracle"] = {"median": float(np.median(rel)), "p90": float(np.quantile(rel, 0.9)), "max": float(rel.max()),
