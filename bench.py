@@ -247,7 +247,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{args.config}: {'PosOrn' if cfg['kind'] == 0 else 'PosOrnTime'} nb_deriv={cfg['nb_deriv']} 7-DoF Panda chain, "
+            "config": {"workload": f"{args.config}: {('PosOrn', 'PosOrnTime', 'JointSpace', 'JointSpaceTime')[cfg['kind']]} nb_deriv={cfg['nb_deriv']} "
+                                   f"{'7-DoF Panda chain' if cfg['kind'] < 2 else str(cfg.get('dof', 7)) + ' joints'}, "
                                    f"T={cfg['T']}, batch {B}/GPU, solver={cfg['solver']}, {nb_iter} iterations/solve, line search on, early stop off",
                        "global_batch": world * B, "horizon": cfg["T"], "iterations_per_step": nb_iter, "parallelism": f"instances sharded x{world}"},
             "batch_sweeps_per_s": nb_iter * args.steps / elapsed,
