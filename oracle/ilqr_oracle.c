@@ -53,6 +53,14 @@ static int is_zero(const double* a, int n) {
    exact arithmetic; tests use the switch to show that an instance's result depends on rounding-level reassociation. */
 static int g_variant = 0;
 void orc_set_variant(int v) { g_variant = v; }
+/* Test aids (see ilqr_oracle.h): decision-margin probe and resume-from-state.  They record / seed, they change no arithmetic. */
+static __thread orc_probe_rec* g_probe = NULL;
+static __thread int g_probe_cap = 0;
+static __thread int g_it0 = 0;
+static __thread double g_init_penalty = 0;
+static __thread const double* g_lambda_mask = NULL;
+void orc_set_probe(orc_probe_rec* buf, int cap) { g_probe = buf; g_probe_cap = buf ? cap : 0; }
+void orc_set_resume(int it0, double init_penalty, const double* lambda_mask) { g_it0 = it0; g_init_penalty = init_penalty; g_lambda_mask = lambda_mask; }
 
 int orc_inverse(int n, const double* A, double* Ainv) {
     double* lu = (double*)malloc(sizeof(double) * n * n);
@@ -594,6 +602,30 @@ static void init_state(const orc_system* s, double* x0) {
     if (s->nb_deriv == 2) memcpy(x0 + dof, s->dq0, sizeof(double) * dof);
 }
 
+/* probe only: smallest distance of a weighted state coordinate of a trajectory to one of its bounds (inspectJointLimit's tests) */
+static double traj_limit_margin(const orc_system* s, const double* X) {
+    double mg = INFINITY;
+    if (!s->limits_set) return mg;
+    for (int k = 0; k < s->T; k++)
+        for (int i = 0; i < s->n_x; i++)
+            if (s->limit_weight[i] != 0) {
+                double xv = X[(size_t)k * s->n_x + i];
+                double a1 = fabs(xv - s->state_max[i]), a2 = fabs(xv - s->state_min[i]);
+                if (a1 < mg) mg = a1;
+                if (a2 < mg) mg = a2;
+            }
+    if (s->limits2_set)
+        for (int k = 0; k < s->T; k++)
+            for (int i = 0; i < s->n_x; i++)
+                if (s->limit_weight2[i] != 0) {
+                    double xv = X[(size_t)k * s->n_x + i];
+                    double a1 = fabs(xv - s->state_max2[i]), a2 = fabs(xv - s->state_min2[i]);
+                    if (a1 < mg) mg = a1;
+                    if (a2 < mg) mg = a2;
+                }
+    return mg;
+}
+
 /* ------------------------------------------------------------------ ILQRRecursive::solve (solver/ILQRRecursive.cpp:21-181)
  * and AL_ILQR::solve (solver/AL-ILQR.cpp:50-232) share this body; c == NULL -> plain recursive. */
 
@@ -627,7 +659,7 @@ static int solve_riccati(const orc_system* s, const orc_constraints* c, double* 
 #define CON_A(k) (c->A + (c->per_step ? (size_t)(k) * m * ns : 0))
 #define CON_B(k) (c->b + (c->per_step ? (size_t)(k) * m : 0))
     /* AL_ILQR::constraints, AL-ILQR.cpp:21-44 (stored pre-multiplied by the current penalty, :72,190) */
-#define CONSTRAINTS(k, xk, uk)                                                                   \
+#define CONSTRAINTS(k, xk, uk, pen_, lam_)                                                       \
     do {                                                                                         \
         double sk[ORC_MAX_NX + ORC_MAX_NU];                                                      \
         memcpy(sk, (xk), sizeof(double) * nx);                                                   \
@@ -635,18 +667,21 @@ static int solve_riccati(const orc_system* s, const orc_constraints* c, double* 
         for (int r_ = 0; r_ < m; r_++) {                                                         \
             double g_ = dot(CON_A(k) + (size_t)r_ * ns, sk, ns) - CON_B(k)[r_];                  \
             double i_ = 1;                                                                       \
-            if (g_ < 0 && lambda[(size_t)(k) * m + r_] == 0) i_ = 0;                              \
-            Is[(size_t)(k) * m + r_] = penalty * i_;                                             \
+            if (g_ < 0 && (lam_)[(size_t)(k) * m + r_] == 0) i_ = 0;                              \
+            if ((lam_)[(size_t)(k) * m + r_] == 0 && fabs(g_) < mask_margin) mask_margin = fabs(g_); /* probe only */ \
+            Is[(size_t)(k) * m + r_] = (pen_) * i_;                                              \
             Cs[(size_t)(k) * m + r_] = g_;                                                       \
         }                                                                                        \
     } while (0)
+    double mask_margin = INFINITY; /* probe: distance of the active-set test g < 0 (rows with lambda == 0) to its threshold */
+    const int resume = (g_it0 > 0);
 
     /* initial rollout: ILQRRecursive.cpp:41-56 / AL-ILQR.cpp:68-85 */
     double cost0 = 0;
     for (int i = 0; i < T - 1; i++) {
         const double* xk = X + (size_t)i * nx;
         const double* uk = U + (size_t)i * nu;
-        if (m) CONSTRAINTS(i, xk, uk);
+        if (m) CONSTRAINTS(i, xk, uk, (resume ? g_init_penalty : penalty), ((resume && g_lambda_mask) ? g_lambda_mask : lambda));
         cost0 += orc_cost(s, xk, uk, i);
         orc_step(s, xk, uk, X + (size_t)(i + 1) * nx, fX + (size_t)(i + 1) * nf,
                  As + (size_t)i * nx * nx, Bs + (size_t)i * nx * nu, NULL);
@@ -731,8 +766,15 @@ static int solve_riccati(const orc_system* s, const orc_constraints* c, double* 
         /* ---------------- forward pass with step-halving line search: ILQRRecursive.cpp:101-155 */
         alpha = 2;
         double newCost = 0, dun = 0;
+        orc_probe_rec* pr = (g_probe && it < g_probe_cap) ? &g_probe[it] : NULL;
+        if (pr) {
+            memset(pr, 0, sizeof(*pr));
+            pr->cost0 = cost0; pr->clamp_margin = INFINITY; pr->limit_margin = INFINITY; pr->mask_margin_in = mask_margin;
+            pr->limit_margin_in = traj_limit_margin(s, X); /* l_xx of the sweep jumps where a coordinate of the incoming trajectory sits on a bound */
+        }
         do {
             alpha /= 2.0;
+            mask_margin = INFINITY;
             init_state(s, nX);
             orc_get_fx_jac(s, nX, nfX, NULL);
             dun = 0;
@@ -749,17 +791,24 @@ static int solve_riccati(const orc_system* s, const orc_constraints* c, double* 
                 for (int i = 0; i < nu; i++) nuk[i] = U[(size_t)k * nu + i] + du[i];
                 orc_step(s, nxk, nuk, nX + (size_t)(k + 1) * nx, nfX + (size_t)(k + 1) * nf,
                          As + (size_t)k * nx * nx, Bs + (size_t)k * nx * nu, NULL); /* last trial's A,B survive (D-7) */
-                if (m) CONSTRAINTS(k, nxk, nuk);
+                if (m) CONSTRAINTS(k, nxk, nuk, penalty, lambda);
                 newCost += orc_cost(s, nxk, nuk, k);
             }
             newCost += orc_cost(s, nX + (size_t)(T - 1) * nx, zero_u, T - 1);
+            if (pr && pr->n_trials < ORC_MAX_TRIALS) { pr->trial_alpha[pr->n_trials] = alpha; pr->trial_cost[pr->n_trials] = newCost; pr->n_trials++; }
         } while (((newCost >= cost0) || isnan(newCost)) && alpha > 1e-3 && line_search);
+        if (pr) { /* probe: margins of the accepted rollout */
+            pr->dun = dun;
+            pr->mask_margin = mask_margin;
+            pr->limit_margin = traj_limit_margin(s, nX);
+        }
 
         /* multiplier update: AL-ILQR.cpp:202-208 (uses the UPDATED penalty) */
-        if (m && ((it + 1) % lag_update_step == 0)) {
+        if (m && ((g_it0 + it + 1) % lag_update_step == 0)) {
             penalty *= scaling;
             for (size_t i = 0; i < (size_t)(T - 1) * m; i++) {
                 double v = lambda[i] + penalty * Cs[i];
+                if (pr && fabs(v) < pr->clamp_margin) pr->clamp_margin = fabs(v);
                 lambda[i] = v > 0 ? v : 0; /* cwiseMax(0) */
             }
         }

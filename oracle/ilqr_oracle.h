@@ -152,6 +152,29 @@ void orc_psi_linear(int dim, int K, double* out);
 int orc_inverse(int n, const double* A, double* Ainv);
 void orc_set_variant(int v);  /* test aid: bit 0 = Qxu := Qux^T in the backward sweep (equal in exact arithmetic) */
 
+/* ---- test aids for the per-instance parity proof (tests/parity_proof.py).  Not part of the restated algorithm: they only RECORD the
+ * quantities the reference's discontinuous decisions are taken on, and let a solve resume from a state handed in from outside.
+ * Thread-local: set and solve on the same thread. */
+#define ORC_MAX_TRIALS 16
+typedef struct {
+    double cost0;                        /* cost of the trajectory the iteration starts from (ILQRRecursive.cpp:155 compares against it) */
+    int n_trials;                        /* line-search trials run (the last one is the accepted one) */
+    double trial_alpha[ORC_MAX_TRIALS];
+    double trial_cost[ORC_MAX_TRIALS];   /* newCost of every trial */
+    double dun;                          /* sum_k ||du_k|| of the accepted trial (early-stop test) */
+    double mask_margin_in;               /* AL: the same margin on the trajectory the iteration STARTS from (its mask feeds this iteration's sweep) */
+    double mask_margin;                  /* AL: min |g| over rows with lambda == 0 on the accepted rollout (AL-ILQR.cpp:38-42); inf if none */
+    double clamp_margin;                 /* AL, update iterations: min |lambda + penalty g| over all rows (AL-ILQR.cpp:205 cwiseMax(0)); inf else */
+    double limit_margin_in;              /* the same on the trajectory the iteration starts from (l_xx of this iteration's sweep) */
+    double limit_margin;                 /* min distance of a weighted state coordinate of the accepted rollout to its bound (l_xx jumps there) */
+} orc_probe_rec;
+void orc_set_probe(orc_probe_rec* buf, int cap); /* buf[it] is filled for it < cap; NULL switches the probe off */
+/* Resume an AL / recursive solve at iteration index it0 (the multiplier-update phase (it+1) % lag counts from it0); for AL the active-set
+ * weights of the trajectory handed in are formed with init_penalty and the multipliers lambda_mask ([T-1][m], the multipliers in force when
+ * that trajectory was rolled out) -- AL-ILQR.cpp:190 stores penalty * I_k at rollout time, before the update of :202-208.  it0 = 0 and
+ * lambda_mask = NULL restore the plain behaviour. */
+void orc_set_resume(int it0, double init_penalty, const double* lambda_mask);
+
 #ifdef __cplusplus
 }
 #endif

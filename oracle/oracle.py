@@ -89,6 +89,16 @@ class System(C.Structure):
     ]
 
 
+MAX_TRIALS = 16
+
+
+class ProbeRec(C.Structure):
+    """orc_probe_rec: what the reference's discontinuous decisions were taken on in one iteration (test aid)."""
+    _fields_ = [("cost0", C.c_double), ("n_trials", C.c_int), ("trial_alpha", C.c_double * MAX_TRIALS), ("trial_cost", C.c_double * MAX_TRIALS),
+                ("dun", C.c_double), ("mask_margin_in", C.c_double), ("mask_margin", C.c_double), ("clamp_margin", C.c_double), ("limit_margin_in", C.c_double),
+                ("limit_margin", C.c_double)]
+
+
 class Constraints(C.Structure):
     _fields_ = [("m", C.c_int), ("per_step", C.c_int), ("A", C.POINTER(C.c_double)), ("b", C.POINTER(C.c_double))]
 
@@ -134,6 +144,10 @@ def lib():
         L.orc_inverse.restype = C.c_int
         L.orc_set_variant.argtypes = [C.c_int]
         L.orc_set_variant.restype = None
+        L.orc_set_probe.argtypes = [C.POINTER(ProbeRec), C.c_int]
+        L.orc_set_probe.restype = None
+        L.orc_set_resume.argtypes = [C.c_int, C.c_double, dp]
+        L.orc_set_resume.restype = None
         for n in ("orc_sd_logmap", "orc_sd_expmap"):
             getattr(L, n).argtypes = [dp, dp, dp]
         L.orc_sd_transport.argtypes = [dp, dp, dp, dp]
@@ -366,20 +380,58 @@ def step(s: System, x, u):
     return xn, fx, A.reshape(s.n_x, s.n_x), B.reshape(s.n_x, s.n_u), J.reshape(s.n_Q, s.n_x)
 
 
-def solve_recursive(s: System, U0, nb_iter, line_search=True, early_stop=True):
+class _Aids:
+    """Arms the oracle's test aids around one solve: the decision-margin probe and / or a resume state (see ilqr_oracle.h)."""
+
+    def __init__(self, nb_iter, probe, resume):
+        self.buf = (ProbeRec * max(nb_iter, 1))() if probe else None
+        self.cap = max(nb_iter, 1)
+        self.resume = resume
+        self._keep = None
+
+    def __enter__(self):
+        L = lib()
+        if self.buf is not None:
+            L.orc_set_probe(self.buf, self.cap)
+        if self.resume:
+            lm = self.resume.get("lambda_mask")
+            self._keep = _arr(lm) if lm is not None else None
+            L.orc_set_resume(int(self.resume["it0"]), float(self.resume.get("init_penalty", 0.0)), _dp(self._keep))
+        return self
+
+    def __exit__(self, *exc):
+        L = lib()
+        L.orc_set_probe(None, 0)
+        L.orc_set_resume(0, 0.0, None)
+
+    def records(self, n):
+        if self.buf is None:
+            return None
+        out = []
+        for i in range(n):
+            r = self.buf[i]
+            out.append(dict(cost0=r.cost0, alpha=list(r.trial_alpha[: r.n_trials]), cost=list(r.trial_cost[: r.n_trials]), dun=r.dun,
+                            mask_margin_in=r.mask_margin_in, mask_margin=r.mask_margin, clamp_margin=r.clamp_margin, limit_margin_in=r.limit_margin_in,
+                            limit_margin=r.limit_margin))
+        return out
+
+
+def solve_recursive(s: System, U0, nb_iter, line_search=True, early_stop=True, probe=False, resume=None):
     T, nx, nu, nf = s.T, s.n_x, s.n_u, s.n_f
     U0 = _arr(U0, (T - 1) * nu)
     X, fX, U = np.zeros((T, nx)), np.zeros((T, nf)), np.zeros((T - 1, nu))
     K, d = np.zeros((T - 1, nu, nx)), np.zeros((T - 1, nu))
     cost_ = np.zeros(1)
     tc, ta = np.full(max(nb_iter, 1), np.nan), np.full(max(nb_iter, 1), np.nan)
-    n = lib().orc_solve_recursive(C.byref(s), _dp(U0), nb_iter, int(line_search), int(early_stop), _dp(X), _dp(fX), _dp(U),
-                                  _dp(K), _dp(d), _dp(cost_), _dp(tc), _dp(ta))
-    return dict(X=X, fX=fX, U=U, K=K, d=d, cost=float(cost_[0]), iters=n, trace_cost=tc[:n], trace_alpha=ta[:n])
+    with _Aids(nb_iter, probe, resume) as aids:
+        n = lib().orc_solve_recursive(C.byref(s), _dp(U0), nb_iter, int(line_search), int(early_stop), _dp(X), _dp(fX), _dp(U),
+                                      _dp(K), _dp(d), _dp(cost_), _dp(tc), _dp(ta))
+    return dict(X=X, fX=fX, U=U, K=K, d=d, cost=float(cost_[0]), iters=n, trace_cost=tc[:n], trace_alpha=ta[:n], probe=aids.records(n))
 
 
-def solve_al(s: System, A, b, lambda0, U0, nb_iter, lag_update_step, penalty, scaling, line_search=True, early_stop=True):
-    """A: (m, n_x+n_u) or (T-1, m, n_x+n_u); b likewise; lambda0: (T-1, m) (copied; returned updated)."""
+def solve_al(s: System, A, b, lambda0, U0, nb_iter, lag_update_step, penalty, scaling, line_search=True, early_stop=True, probe=False, resume=None):
+    """A: (m, n_x+n_u) or (T-1, m, n_x+n_u); b likewise; lambda0: (T-1, m) (copied; returned updated).
+    probe: also return the per-iteration decision margins; resume: dict(it0, init_penalty, lambda_mask) (test aids, ilqr_oracle.h)."""
     T, nx, nu, nf = s.T, s.n_x, s.n_u, s.n_f
     A, b = _arr(A), _arr(b)
     per_step = 1 if A.ndim == 3 else 0
@@ -390,9 +442,10 @@ def solve_al(s: System, A, b, lambda0, U0, nb_iter, lag_update_step, penalty, sc
     X, fX, U = np.zeros((T, nx)), np.zeros((T, nf)), np.zeros((T - 1, nu))
     cost_ = np.zeros(1)
     tc, ta = np.full(max(nb_iter, 1), np.nan), np.full(max(nb_iter, 1), np.nan)
-    n = lib().orc_solve_al(C.byref(s), C.byref(c), _dp(lam), _dp(U0), nb_iter, lag_update_step, penalty, scaling,
-                           int(line_search), int(early_stop), _dp(X), _dp(fX), _dp(U), _dp(cost_), _dp(tc), _dp(ta))
-    return dict(X=X, fX=fX, U=U, cost=float(cost_[0]), iters=n, trace_cost=tc[:n], trace_alpha=ta[:n], lam=lam)
+    with _Aids(nb_iter, probe, resume) as aids:
+        n = lib().orc_solve_al(C.byref(s), C.byref(c), _dp(lam), _dp(U0), nb_iter, lag_update_step, penalty, scaling,
+                               int(line_search), int(early_stop), _dp(X), _dp(fX), _dp(U), _dp(cost_), _dp(tc), _dp(ta))
+    return dict(X=X, fX=fX, U=U, cost=float(cost_[0]), iters=n, trace_cost=tc[:n], trace_alpha=ta[:n], lam=lam, probe=aids.records(n))
 
 
 def solve_batch_cp(s: System, psi, u0, nb_iter, early_stop=True):

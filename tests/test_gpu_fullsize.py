@@ -7,7 +7,8 @@ minutes: size-independent properties plus a sample of instances against the orac
   wave or the workgroup an instance lands in);
 * the returned trajectory is the rollout of the returned controls (oracle dynamics), and for the recursive solver the returned
   cost is the reference's cost of that trajectory (oracle cost function);
-* a seeded sample of instances agrees with the oracle in final cost within the north star's 1e-4 (median 1e-6)."""
+* a seeded sample of instances agrees with the oracle in final cost within the north star's 1e-4 (median 1e-6) or -- Riccati
+  solvers -- is proven iteration by iteration (tests/parity_proof.py): no share of the sample is excused."""
 import numpy as np
 import pytest
 
@@ -34,7 +35,7 @@ def _take(inp, idx):
     return out
 
 
-def _solve(ctx, cfg, desc, inp, B, nb_iter, solver):
+def _solve(ctx, cfg, desc, inp, B, nb_iter, solver, keep=False):
     from ilqr_planner_amd import workloads
 
     p = workloads.load_batch(ctx, desc, inp, B)
@@ -45,7 +46,10 @@ def _solve(ctx, cfg, desc, inp, B, nb_iter, solver):
     else:
         workloads.run_solver(p, cfg, nb_iter=nb_iter, early_stop=False)
     out = dict(cost=p.cost(), U=p.U(), X=p.X(), iters=p.iters(), alpha=p.alpha(), trace=p.trace(nb_iter)[0])
-    p.close()
+    if keep:
+        out["p"] = p
+    else:
+        p.close()
     return out
 
 
@@ -68,7 +72,8 @@ def test_full_size_properties(ctx, cfg_name, B, nb_iter, solver):
     rng = np.random.default_rng(7)
     idx = np.sort(rng.choice(B, 61, replace=False))  # ragged: not a multiple of the wave size
     desc_s, _ = workloads.make_batch(ctx, cfg, B=len(idx))
-    small = _solve(ctx, cfg, desc_s, _take(inp, idx), len(idx), nb_iter, solver)
+    inp_s = _take(inp, idx)
+    small = _solve(ctx, cfg, desc_s, inp_s, len(idx), nb_iter, solver, keep=solver in ("al", "recursive"))
     np.testing.assert_array_equal(small["cost"], big["cost"][idx])
     np.testing.assert_array_equal(small["U"], big["U"][idx])
     np.testing.assert_array_equal(small["X"], big["X"][idx])
@@ -104,8 +109,15 @@ def test_full_size_properties(ctx, cfg_name, B, nb_iter, solver):
     rel = np.asarray(rel)
     assert len(rel) >= len(sample) // 3
     assert np.median(rel) <= 1e-6, f"median rel err {np.median(rel):.2e}"
-    # AL-iLQR over 20 iterations without early stop is a discontinuous map (active-set mask, accept-anyway line search): the oracle's
-    # own final cost moves by 1e-6..1e-1 under 1e-15 input perturbations on such instances (tests/test_gpu_parity.py shows it per
-    # instance); here only the share of the sample within the bound is asserted
-    share = 0.75 if solver == "al" else 0.85
-    assert (rel <= 1e-4).mean() >= share, f"{(rel > 1e-4).sum()} of {len(rel)} sampled instances outside 1e-4 (max {rel.max():.2e})"
+    if solver in ("al", "recursive"):
+        # the 61-instance cut-out is bit-identical to the big batch (asserted above), so the per-instance proof runs on it: every instance
+        # of it is within 1e-4 of the oracle's end-to-end run or each of its iterations is reproduced by the oracle from the GPU's state
+        from tests import parity_proof as pp
+
+        summ, _, failures = pp.check_batch(small["p"], cfg, inp_s, nb_iter, False, workloads.run_solver,
+                                           lambda i: oracle_solve_instance(cfg, inp_s, i, nb_iter, False, segs), always=(0, 1))
+        small["p"].close()
+        print(f"parity {cfg_name} full size: {summ}")
+        assert not failures, f"{len(failures)} instance(s) neither within 1e-4 nor proven: {failures[:3]}"
+    else:  # batch solvers: Gauss-Newton with backtracking on the true cost, compared end to end
+        assert (rel <= 1e-4).mean() >= 0.85, f"{(rel > 1e-4).sum()} of {len(rel)} sampled instances outside 1e-4 (max {rel.max():.2e})"

@@ -110,35 +110,40 @@ def test_tutorial_traces_on_gpu(ctx, name, idx, hip_path):
                                                        ("C2hl", 48, 12, "urdf"),
                                                        ("C2ndal", 32, 10, "inactive"), ("C4t1al", 32, 10, "inactive"),  # AL on the 2nd-order and time systems
                                                        ("C1jal", 32, 8, "inactive"), ("C1tal", 32, 8, "inactive")])  # ... and on the joint-space systems  # ... whose sub-systems have different bounds (second limit set)  # JointSpacePlannerSys (C1 = BASELINE configs[0])
-def test_random_batch_vs_oracle(ctx, cfg_name, B, nb_iter, limits):
-    """Seeded random batches: final cost within 1e-4 relative of the oracle.
+def test_random_batch_vs_oracle(ctx, cfg_name, B, nb_iter, limits, hip_path):
+    """Seeded random batches: every instance ends within 1e-4 relative of the oracle's own end-to-end run, or is PROVEN iteration by
+    iteration (tests/parity_proof.py): each iteration the GPU made is reproduced by ONE oracle iteration from the GPU's own state
+    (same alpha, cost within 1e-9), or is decided by a rounding-level tie in the oracle's own decision (line search, active-set mask,
+    limit, early stop) read from the oracle's probe.  No share of a batch is excused; a NaN on one side only is never excused.
 
-    iLQR with the reference's accept-anyway line search (and, for AL, the active-set mask `g<0 && lambda==0`) is a
-    discontinuous map: on a few ill-conditioned instances a 1e-15 perturbation of q0 moves the ORACLE's own final cost
-    by 1e-6..1e-2 (measured; see DESIGN.md "Parity").  An instance may therefore miss the 1e-4 bound only if the
-    oracle itself is shown to be that sensitive there, and at most 10 % of a batch may do so."""
+    iLQR with the reference's accept-anyway line search is an expanding map far from convergence (a full step raises the cost 1e6-fold on
+    some C3 instances), so rounding differences of 1e-13 per iteration can grow to 1e-1 over 20 iterations: that is why the end-to-end
+    comparison alone cannot be the gate (DESIGN.md "Parity")."""
     from ilqr_planner_amd import workloads
+    from tests import parity_proof as pp
 
     cfg = workloads.config(cfg_name)
     desc, inp = workloads.make_batch(ctx, cfg, B=B, limits=limits)  # "urdf": the joint limits of the Panda, active penalties
     p = workloads.load_batch(ctx, desc, inp, B)
     workloads.run_solver(p, cfg, nb_iter=nb_iter, early_stop=True)
     cost, iters, X, U = p.cost(), p.iters(), p.X(), p.U()
-    ct, at = p.trace(nb_iter)
+    at = p.trace(nb_iter)[1]
     segs = panda_segs()
-    rel = np.zeros(B)
-    excused = 0
-    for i in range(B):
-        r = oracle_solve_instance(cfg, inp, i, nb_iter, True, segs)
-        if not np.isfinite(r["cost"]):  # the reference itself diverges on some time-system instances (SURVEY App. D-12)
-            if np.isfinite(cost[i]):
-                excused += 1  # NaN onset is itself a discontinuity: counts against the 10 % allowance
-            continue
-        if not np.isfinite(cost[i]):
-            excused += 1
-            rel[i] = 0.0
-            continue
-        rel[i] = abs(cost[i] - r["cost"]) / max(abs(r["cost"]), 1e-12)
+    orc_res = {}
+
+    def oracle_solve(i):
+        orc_res[i] = oracle_solve_instance(cfg, inp, i, nb_iter, True, segs)
+        return orc_res[i]
+
+    summ, rel, failures = pp.check_batch(p, cfg, inp, nb_iter, True, workloads.run_solver, oracle_solve)
+    p.close()
+    print(f"parity[{hip_path}] {cfg_name} B={B}: {summ}")
+    assert not failures, f"{len(failures)} instance(s) neither within 1e-4 nor proven: {failures[:3]}"
+    assert summ["frac_unexplained"] == 0.0
+    fin = np.isfinite(rel)
+    assert np.median(rel[fin]) <= 1e-6, f"median rel err {np.median(rel[fin]):.2e}"
+    for i in range(B):  # where GPU and oracle took the same path, the trajectories agree too
+        r = orc_res[i]
         same_path = iters[i] == r["iters"] and np.array_equal(at[i, : r["iters"]], r["trace_alpha"])
         if same_path and rel[i] <= 1e-7 and limits == "inactive":  # (active penalties add kinks: equal costs, trajectories apart by 1e-3)
             # the arm is redundant (7 joints, 6-D task, R = 1e-5): trajectories are only weakly determined along the
@@ -146,44 +151,6 @@ def test_random_batch_vs_oracle(ctx, cfg_name, B, nb_iter, limits):
             nxo, nuo = r["X"].shape[1], r["U"].shape[1]  # joint-space batches are padded to 7 joints on the device
             np.testing.assert_allclose(X[i][:, :nxo], r["X"], rtol=0, atol=2e-4)
             np.testing.assert_allclose(U[i][:, :nuo], r["U"], rtol=0, atol=2e-3)
-        if rel[i] > COST_RTOL:
-            # perturb the oracle's inputs at rounding level: q0[0] by a few 1e-15, then q0 and U0 by 1e-14 noise (a reordered
-            # sum in a kernel perturbs every gain entry by a few ulps, which a single-coordinate nudge does not span)
-            worst = 0.0
-            prng = np.random.default_rng(1000 + i)
-            trials = [("variant", 1)] + [("q0", eps) for eps in (1e-15, -1e-15, 2e-15)] + [("noise", t) for t in range(6)]
-            for kind, val in trials:
-                inp2 = dict(inp)
-                if kind == "variant":  # the oracle's own sweep with Qxu := Qux^T (equal in exact arithmetic; the time systems'
-                    # Riccati recursion amplifies such reassociations: P spans ten orders of magnitude)
-                    import oracle.oracle as orc_mod
-                    orc_mod.set_variant(1)
-                    try:
-                        r2 = oracle_solve_instance(cfg, inp2, i, nb_iter, True, segs)
-                    finally:
-                        orc_mod.set_variant(0)
-                    worst = max(worst, abs(r2["cost"] - r["cost"]) / max(abs(r["cost"]), 1e-12))
-                    if worst >= 1e-7:
-                        break
-                    continue
-                q = inp["q0"].copy()
-                if kind == "q0":
-                    q[i, 0] += val
-                else:
-                    q[i] += 1e-14 * prng.standard_normal(q.shape[1])
-                    u = inp["U0"].copy()
-                    u[i] += 1e-14 * prng.standard_normal(u[i].shape)
-                    inp2["U0"] = u
-                inp2["q0"] = q
-                r2 = oracle_solve_instance(cfg, inp2, i, nb_iter, True, segs)
-                worst = max(worst, abs(r2["cost"] - r["cost"]) / max(abs(r["cost"]), 1e-12))
-                if worst >= 1e-7:
-                    break
-            assert worst >= 1e-7, f"instance {i}: rel err {rel[i]:.2e} but the oracle is well conditioned there ({worst:.1e})"
-            excused += 1
-    assert np.median(rel) <= 1e-6, f"median rel err {np.median(rel):.2e}"
-    assert excused <= B // 10, f"{excused} of {B} instances outside 1e-4 (max {rel.max():.2e})"
-    p.close()
 
 
 def test_gains_and_fx_outputs(ctx):
@@ -230,8 +197,8 @@ def test_fk_batch_vs_oracle(ctx):
 @pytest.mark.parametrize("per_step,with_control_row", [(False, True), (True, False), (True, True)])
 def test_al_constraint_shapes(ctx, per_step, with_control_row):
     """AL-iLQR beyond the tutorial's single shared state row: several rows, bounds that change with the timestep (one constraint set
-    per step, AL-ILQR.h:20-36), rows on the controls (these leave the closed-form sweep for the generic one).  Final cost against the
-    oracle under the same sensitivity rule as the random batches."""
+    per step, AL-ILQR.h:20-36), rows on the controls (these leave the closed-form sweep for the generic one).  Same gate as the
+    random batches: within 1e-4 of the oracle's end-to-end run, or proven iteration by iteration (tests/parity_proof.py)."""
     from ilqr_planner_amd import workloads
 
     cfg = dict(workloads.config("C3"), T=60)
@@ -252,21 +219,21 @@ def test_al_constraint_shapes(ctx, per_step, with_control_row):
     p.set_constraints(A, b, lam0)
     al = cfg["al"]
     p.solve_al(nb_iter, al["lag"], al["penalty"], al["scaling"], True, True)
-    cost, at = p.cost(), p.trace(nb_iter)[1]
-    p.close()
+    from tests import parity_proof as pp
     from tests.helpers import oracle_system_of_instance
 
-    rel, same = [], 0
-    for i in range(B):
+    inp2 = dict(inp, A=A, b=b, lambda0=lam0)  # the constraint set of this test, for the oracle replays
+
+    def oracle_solve(i):
         s = oracle_system_of_instance(cfg, inp, i)
-        r = orc.solve_al(s, A, b, lam0[i], inp["U0"][i].reshape(-1), nb_iter, al["lag"], al["penalty"], al["scaling"], True, True)
-        if not (np.isfinite(r["cost"]) and np.isfinite(cost[i])):
-            continue
-        rel.append(abs(cost[i] - r["cost"]) / max(abs(r["cost"]), 1e-12))
-        same += int(np.array_equal(at[i][: r["iters"]], r["trace_alpha"]))
-    rel = np.asarray(rel)
-    assert len(rel) >= B // 2 and np.median(rel) <= 1e-6, f"median rel err {np.median(rel):.2e}"
-    assert (rel <= COST_RTOL).mean() >= 0.8, f"{(rel > COST_RTOL).sum()} of {len(rel)} outside 1e-4 (max {rel.max():.2e})"
+        return orc.solve_al(s, A, b, lam0[i], inp["U0"][i].reshape(-1), nb_iter, al["lag"], al["penalty"], al["scaling"], True, True)
+
+    summ, rel, failures = pp.check_batch(p, cfg, inp2, nb_iter, True, workloads.run_solver, oracle_solve)
+    p.close()
+    print(f"parity AL shapes per_step={per_step} control_row={with_control_row}: {summ}")
+    assert not failures, f"{len(failures)} instance(s) neither within 1e-4 nor proven: {failures[:3]}"
+    fin = np.isfinite(rel)
+    assert fin.sum() >= B // 2 and np.median(rel[fin]) <= 1e-6, f"median rel err {np.median(rel[fin]):.2e}"
 
 
 def test_empty_and_ragged_inputs(ctx):
