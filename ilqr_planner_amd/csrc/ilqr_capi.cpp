@@ -313,8 +313,7 @@ extern "C" int ilqr_problem_create(ilqr_ctx* c, const ilqr_problem_desc* d, int 
     p->Bp = (batch + 63) / 64 * 64;
     // Row stride of every [row][Bp] buffer is Bp*8 bytes.  A power-of-two stride (Bp = 4096 -> 32 KiB) maps the 49 rows
     // of a K block onto the same L2 sets / HBM channel; one extra 64-instance pad column breaks the alignment.
-    if (const char* e = std::getenv("ILQR_BP_PAD")) { p->Bp += 64 * std::atoi(e); }
-    else if (p->Bp % 512 == 0) p->Bp += 64;
+    if (p->Bp % 512 == 0) p->Bp += 64;
     p->T = d->horizon;
     if (ilqr_dims_of(d, &p->dims) || lower_desc(c, *d, p->B, p->Bp, p->hdesc)) { delete p; return 1; }
     const int T = p->T, NX = p->dims.n_x, NU = p->dims.n_u, NF = p->dims.n_f, Bp = p->Bp;
@@ -480,15 +479,13 @@ static int ensure_trace(ilqr_problem* p, int nb_iter) {
     return 0;
 }
 
-// Which kernels run an iteration.  v2 (default): closed-form single-integrator sweep where it applies, alpha-parallel
-// line search everywhere.  ILQR_HIP_PATH=v1 forces the generic lane-per-instance kernels (used by the parity tests to
-// cross-check the two paths); ILQR_HIP_PATH=v2fwd keeps the generic sweep with the alpha-parallel forward.
+// Which kernels run an iteration.  Default ("v2"): cooperative kernels -- closed-form single-integrator sweep or the f64-MFMA sweep, all
+// step sizes of the line search in one pass.  ILQR_HIP_PATH=v1 forces the generic lane-per-instance kernels, the cross-check set of
+// the parity tests (also the product path where the cooperative kernels do not apply: joint-space AL rows on the controls, more
+// than 16 AL rows, a second limit set).  This is the library's only environment switch; it is read at every solve.
 static int path_choice() {
     const char* e = std::getenv("ILQR_HIP_PATH");
-    if (!e) return 2;
-    if (!std::strcmp(e, "v1")) return 1;
-    if (!std::strcmp(e, "v2fwd")) return 3;
-    return 2;
+    return (e && !std::strcmp(e, "v1")) ? 1 : 2;
 }
 
 static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double penalty, double scaling, int line_search, int early_stop) {
@@ -505,23 +502,22 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
     int n_alpha = 1;
     if (line_search) { double al_ = 1.0; while (al_ > p->desc.alpha_floor && n_alpha < 64) { al_ *= 0.5; n_alpha++; } }
     const int path = p->desc.limits2_set ? 1 : path_choice();  // a second limit set exists in the generic kernels only
-    const bool fwd_tile = (path != 1) && n_alpha <= 16;
-    const char* fwd_env = std::getenv("ILQR_FWD");
-    const bool fwd_rows = fwd_tile && forward_rows_supported(kind, nd, n_alpha) && !(fwd_env && !std::strcmp(fwd_env, "tile"));
-    const bool fwd_lin = fwd_rows && !(fwd_env && !std::strcmp(fwd_env, "rows"));  // linear line search (PosOrn systems)
-    const bool fwd_wave = fwd_tile && forward_wave_supported(kind, nd, n_alpha) && !(fwd_env && (!std::strcmp(fwd_env, "tile") || !std::strcmp(fwd_env, "rows")));  // 32 lanes per instance + k_select
-    const bool bwd_si = (path == 2) && backward_si_supported(kind, nd, al, p->bufs.m, p->bufs.per_step, p->con_state_only);
-    const bool bwd_mfma = (path == 2) && !bwd_si && backward_mfma_supported(kind, nd, al, p->bufs.m);  // wave per instance, f64 matrix cores
-    const bool bwd_gen = (path == 2) && !bwd_si && !bwd_mfma && backward_gen_supported(kind, nd, al, p->bufs.m);  // same, VALU + LDS products
+    const bool coop = (path != 1) && n_alpha <= 16;            // all step sizes at once (16 lanes / rows per instance)
+    const bool fwd_wave = coop && forward_wave_supported(kind, nd, n_alpha);  // PosOrn-1 / JointSpace-1: linear line search, 32 lanes per instance
+    const bool fwd_lin = coop && !fwd_wave && forward_lin_supported(kind, nd, n_alpha);  // PosOrn-2: linear line search, 8 lanes per instance
+    const bool bwd_si = (path != 1) && backward_si_supported(kind, nd, al, p->bufs.m, p->bufs.per_step, p->con_state_only);
+    const bool bwd_mfma = (path != 1) && !bwd_si && backward_mfma_supported(kind, nd, al, p->bufs.m);  // wave per instance, f64 matrix cores
+    const bool fused = bwd_si && fwd_wave;  // the sweep applies the previous line search's winner itself (ilqr_kernels_coop.hip)
     FwdArgs f;
     std::memset(&f, 0, sizeof(f));
     f.line_search = line_search; f.early_stop = early_stop; f.nb_iter = nb_iter; f.penalty_roll = penalty; f.n_alpha = n_alpha; f.al = al ? 1 : 0; f.n_kp = p->desc.n_kp;
+    f.fused = fused ? 1 : 0;
     for (int k = 0; k < p->desc.n_kp; k++) f.kp_ext |= p->desc.kp_dist[k] | p->desc.kp_has_frame[k] | p->desc.kp_has_Ru[k] | p->desc.kp_joint[k];
     {
         ProfScope ps(c, ILQR_PROF_ROLLOUT);
         if (path != 1 && init_lti_supported(kind, nd)) {
             launch_init_lti(kind, nd, p->bufs, p->B, c->stream);
-            if (al) {  // active-set weights of the initial trajectory: I_k = penalty * (g<0 && lambda==0 ? 0 : 1)
+            if (al && !fused) {  // active-set weights of the initial trajectory: I_k = penalty * (g<0 && lambda==0 ? 0 : 1)
                 f.it = -1; f.do_update = 0;
                 launch_solver_v2(kind, nd, KER_AL_UPDATE, al, p->bufs, p->B, p->T, c->stream, f);
             }
@@ -530,16 +526,17 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
         }
     }
     HIPCHK(c, hipGetLastError());
+    SweepArgs sw;
+    sw.pen_in = penalty; sw.pen_update_prev = penalty; sw.do_update_prev = 0;
     for (int it = 0; it < nb_iter; it++) {
         {
-            if (bwd_si || bwd_gen || bwd_mfma) {
+            {   // l_x, l_xx at the keypoint steps (FK, log map, J'QJ) for every sweep: none of them holds keypoint code
                 ProfScope ps(c, ILQR_PROF_OTHER);
-                launch_solver_v2(kind, nd, KER_KP_DERIVS, al, p->bufs, p->B, p->T, c->stream, f);
+                launch_solver(kind, nd, KER_KP_DERIVS, al, p->bufs, p->B, c->stream, f);
             }
             ProfScope ps(c, ILQR_PROF_BACKWARD);
-            if (bwd_si) launch_solver_v2(kind, nd, KER_BACKWARD_SI, al, p->bufs, p->B, p->T, c->stream, f);
+            if (bwd_si) launch_backward_si_coop(al, fused, p->bufs, p->B, c->stream, sw);
             else if (bwd_mfma) launch_backward_mfma(kind, nd, al, p->bufs, p->B, c->stream);
-            else if (bwd_gen) launch_backward_gen(kind, nd, al, p->bufs, p->B, c->stream);
             else launch_solver(kind, nd, KER_BACKWARD, al, p->bufs, p->B, c->stream, f);
         }
         f.it = it;
@@ -547,26 +544,25 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
         f.do_update = al && ((it + 1) % lag == 0);
         if (f.do_update) penalty *= scaling;  // multipliers use the UPDATED penalty (AL-ILQR.cpp:203-205)
         f.penalty_update = penalty;
-        if (fwd_tile) {
+        sw.pen_in = f.penalty_roll; sw.pen_update_prev = f.penalty_update; sw.do_update_prev = f.do_update;  // for the next sweep
+        if (coop) {
             {
                 ProfScope ps(c, ILQR_PROF_FORWARD);
                 if (fwd_wave) launch_forward_wave(kind, p->bufs, p->B, c->stream, f);
                 else if (fwd_lin) launch_forward_lin(nd, KER_FWD_SPEC, p->bufs, p->B, p->T, c->stream, f);
-                else if (fwd_rows) launch_forward_rows(nd, KER_FWD_SPEC, p->bufs, p->B, c->stream, f);
                 else launch_solver_v2(kind, nd, KER_FWD_SPEC, al, p->bufs, p->B, p->T, c->stream, f);
             }
-            if (fwd_wave) {  // winner applied, AL bookkeeping and buffer flip in one pass over the trajectory
+            if (fwd_wave) {  // winner applied, AL bookkeeping and buffer flip in one pass over the trajectory -- or by the next sweep (fused)
+                if (!fused || it == nb_iter - 1) {
+                    ProfScope ps(c, ILQR_PROF_APPLY);
+                    launch_apply_wave(kind, p->bufs, p->B, p->T, c->stream, f);
+                }
+            } else if (fwd_lin) {  // the cost pass writes no trajectory: the winner is always re-rolled
                 ProfScope ps(c, ILQR_PROF_APPLY);
-                launch_apply_wave(kind, p->bufs, p->B, p->T, c->stream, f);
-            } else if (fwd_rows) {  // the cost pass writes no trajectory: the winner is always re-rolled
+                launch_forward_lin(nd, KER_FWD_APPLY, p->bufs, p->B, p->T, c->stream, f);
+            } else if (line_search) {  // time systems: re-roll of the winner where the speculated step size lost, 8 lanes per instance
                 ProfScope ps(c, ILQR_PROF_APPLY);
-                if (fwd_lin) launch_forward_lin(nd, KER_FWD_APPLY, p->bufs, p->B, p->T, c->stream, f);
-                else launch_forward_rows(nd, KER_FWD_APPLY, p->bufs, p->B, c->stream, f);
-            } else if (line_search) {
-                ProfScope ps(c, ILQR_PROF_APPLY);
-                static const bool tile_apply = std::getenv("ILQR_APPLY") && !std::strcmp(std::getenv("ILQR_APPLY"), "tile");
-                if ((kind == 1 || kind == 3) && !tile_apply) launch_apply_rows_tm(kind, nd, p->bufs, p->B, c->stream, f);  // 8 lanes per instance
-                else launch_solver_v2(kind, nd, KER_FWD_APPLY, al, p->bufs, p->B, p->T, c->stream, f);
+                launch_apply_rows_tm(kind, nd, p->bufs, p->B, c->stream, f);
             }
             if (al && !fwd_wave) {  // active-set weights of the accepted trajectory (+ multiplier update every `lag` iterations)
                 ProfScope ps(c, ILQR_PROF_OTHER);
@@ -593,6 +589,7 @@ extern "C" int ilqr_solve_batch_cp(ilqr_problem* p, const double* psi, int Kw, i
     if (!p) return 1;
     ilqr_ctx* c = p->ctx;
     if (!p->has_state || !p->has_controls) return fail(c, "set_init_state and set_controls must be called before a solve");
+    HIPCHK(c, hipSetDevice(c->device));
     std::string err;
     if (ensure_trace(p, nb_iter)) return 1;
     p->last_nb_iter = nb_iter;
@@ -610,6 +607,7 @@ extern "C" int ilqr_solve_batch(ilqr_problem* p, int nb_iter, int early_stop) {
     if (!p) return 1;
     ilqr_ctx* c = p->ctx;
     if (!p->has_state || !p->has_controls) return fail(c, "set_init_state and set_controls must be called before a solve");
+    HIPCHK(c, hipSetDevice(c->device));
     std::string err;
     if (ensure_trace(p, nb_iter)) return 1;
     p->last_nb_iter = nb_iter;

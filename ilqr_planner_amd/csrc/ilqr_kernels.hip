@@ -64,7 +64,60 @@ __global__ __launch_bounds__(64) void k_init_rollout(Bufs a, double penalty) {
     a.status[b] = isfinite(cost) ? 0 : 1;
 }
 
-// Backward Riccati sweep (ILQRRecursive.cpp:68-97): writes K_k, d_k for k = T-2..0.
+// l_x, l_xx of the keypoint steps (System::cost_x / cost_xx incl. the limit terms) for the current trajectory, one lane per
+// (instance, keypoint).  Keeps FK, the quaternion log map and J'QJ out of the sequential sweep: the sweep only loads
+// NX + NX*NX doubles at the (two) keypoint steps.
+template <class S, bool EXT>
+__global__ __launch_bounds__(64) void k_kp_derivs(Bufs a, int fused) {
+    constexpr int NX = S::NX;
+    const DevDesc& d = *a.desc;
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    const int kpi = blockIdx.y;
+    if (b >= d.B) return;
+    if (!a.active[b]) return;
+    const int Bp = d.Bp;
+    const int k = d.kp_t[kpi];
+    const int cur = a.cur[b];
+    const double* X = a.X[cur];
+    double x[NX], lxx[NX][NX], lx[NX];
+    UNR for (int i = 0; i < NX; i++) x[i] = AT(X, k * NX + i, b);
+    const int w = fused ? a.pend[b] - 1 : -1;
+    if (w >= 0) {  // fused acceptance (FwdArgs::fused): the accepted state is still spread over the two buffers -- k_apply's expression
+        const double aa = ldexp(1.0, -w);
+        const double* X1 = a.X[1 - cur];
+        UNR for (int i = 0; i < NX; i++) {
+            const double x1 = AT(X1, k * NX + i, b);
+            x[i] = (w == 0) ? x1 : fma(aa, x1 - x[i], x[i]);
+        }
+    }
+    stage_derivs<S, true, EXT>(d, a, b, x, kpi, lxx, lx);
+    double* out = a.kpd + (size_t)kpi * (NX + NX * NX) * Bp;
+    UNR for (int i = 0; i < NX; i++) {
+        AT(out, i, b) = lx[i];
+        UNR for (int j = 0; j < NX; j++) AT(out, NX + i * NX + j, b) = lxx[i][j];
+    }
+}
+
+// l_x, l_xx of a stage for the generic sweep: at the keypoint steps the values k_kp_derivs stored for the current trajectory (FK, the
+// quaternion log map, frames, dead zones and J'QJ stay out of the sweep: inlined here they made it a 19 000-line kernel at 512 VGPRs
+// with kilobytes of scratch per lane), elsewhere the limit terms; the second limit set on top of either.
+template <class S>
+ILQR_DEV void sweep_stage_derivs(const DevDesc& d, const Bufs& a, int b, int kpi, const double* x, double (*lxx)[S::NX], double* lx) {
+    constexpr int NX = S::NX;
+    const int Bp = d.Bp;
+    if (kpi >= 0) {
+        const double* src = a.kpd + (size_t)kpi * (NX + NX * NX) * Bp;
+        UNR for (int i = 0; i < NX; i++) {
+            lx[i] = AT(src, i, b);
+            UNR for (int j = 0; j < NX; j++) lxx[i][j] = AT(src, NX + i * NX + j, b);
+        }
+    } else {
+        stage_derivs<S>(d, a, b, x, -1, lxx, lx);
+    }
+    if (d.lim2) lim2_derivs<S>(d, x, lxx, lx);
+}
+
+// Backward Riccati sweep (ILQRRecursive.cpp:68-97): writes K_k, d_k for k = T-2..0.  Needs k_kp_derivs first.
 template <class S, bool AL>
 __global__ __launch_bounds__(64) void k_backward(Bufs a) {
     constexpr int NX = S::NX, NU = S::NU, ND = S::ND, TM = S::TM;
@@ -81,11 +134,7 @@ __global__ __launch_bounds__(64) void k_backward(Bufs a) {
     UNR for (int i = 0; i < NX; i++) x[i] = AT(X, (T - 1) * NX + i, b);
     {
         const bool iskp = (kpi >= 0 && d.kp_t[kpi] == T - 1);
-        // the keypoint code (FK, log map, frames, J'QJ) is called out of line: inlined twice into this kernel it drove the register
-        // allocator into spilling SGPRs to VGPR lanes
-        if (iskp) stage_derivs_call<S>(&d, &a, b, kpi, x, &P[0][0], p);
-        else stage_derivs<S>(d, a, b, x, -1, P, p);
-        if (d.lim2) lim2_derivs<S>(d, x, P, p);
+        sweep_stage_derivs<S>(d, a, b, iskp ? kpi : -1, x, P, p);
         if (iskp) kpi--;
     }
     for (int k = T - 2; k >= 0; k--) {
@@ -111,9 +160,7 @@ __global__ __launch_bounds__(64) void k_backward(Bufs a) {
         double lxx[NX][NX], lx[NX];
         {
             const bool iskp = (kpi >= 0 && d.kp_t[kpi] == k);
-            if (iskp) stage_derivs_call<S>(&d, &a, b, kpi, x, &lxx[0][0], lx);
-            else stage_derivs<S>(d, a, b, x, -1, lxx, lx);
-            if (d.lim2) lim2_derivs<S>(d, x, lxx, lx);
+            sweep_stage_derivs<S>(d, a, b, iskp ? kpi : -1, x, lxx, lx);
             if (iskp) kpi--;
         }
         // BtP = B^T P (NU x NX), AtP = A^T P (NX x NX)
@@ -446,6 +493,10 @@ template <class S>
 static void launch_solver_kernel(int which, bool al, const Bufs& a, int B, hipStream_t st, const FwdArgs& f) {
     const dim3 grid((B + 63) / 64), block(64);
     switch (which) {
+        case KER_KP_DERIVS:
+            if (f.n_kp > 0 && f.kp_ext) hipLaunchKernelGGL((k_kp_derivs<S, true>), dim3((B + 63) / 64, f.n_kp), dim3(64), 0, st, a, f.fused);
+            else if (f.n_kp > 0) hipLaunchKernelGGL((k_kp_derivs<S, false>), dim3((B + 63) / 64, f.n_kp), dim3(64), 0, st, a, f.fused);
+            break;
         case KER_INIT:
             if (al) hipLaunchKernelGGL((k_init_rollout<S, true>), grid, block, 0, st, a, f.penalty_roll);
             else hipLaunchKernelGGL((k_init_rollout<S, false>), grid, block, 0, st, a, f.penalty_roll);

@@ -52,27 +52,32 @@ struct FwdArgs {
     int n_alpha;  // number of step sizes 1, 1/2, ... the line search may try (11 for alpha_floor = 1e-3)
     double penalty_roll, penalty_update;
     int kp_ext;   // some keypoint has a dead zone, an object frame or its own control penalty (selects the full keypoint code)
+    int fused;    // the acceptance of the line search is applied by the next sweep (k_backward_si_coop<.., true>): until then the accepted
+                  // trajectory of an instance with pend > 0 is xbar + alpha (x(1) - xbar) over its two buffers
+};
+
+// Fused acceptance in the cooperative sweep: what k_apply would have used at the end of the PREVIOUS iteration
+struct SweepArgs {
+    double pen_in;           // penalty the active-set weights of the incoming trajectory are formed with (AL-ILQR.cpp:190)
+    double pen_update_prev;  // penalty of the previous iteration's multiplier update (AL-ILQR.cpp:203-205)
+    int do_update_prev;      // the previous iteration was an update iteration
 };
 
 // v1 (one lane per instance, generic): KER_INIT, KER_BACKWARD, KER_FORWARD
 // v2: KER_FWD_SPEC  = all n_alpha line-search trials of an instance at once (16 lanes per instance), K read once
 //     KER_FWD_APPLY = re-roll the winning step size for the instances whose winner was not alpha = 1
 //     KER_AL_UPDATE = multiplier update on the accepted trajectory
-//     KER_BACKWARD_SI = closed-form Riccati step for single-integrator dynamics (PosOrn, nb_deriv = 1)
-//     KER_KP_DERIVS = l_x, l_xx at the keypoint steps (FK + Jacobian), one lane per (instance, keypoint), feeding KER_BACKWARD_SI
-enum { KER_INIT = 0, KER_BACKWARD = 1, KER_FORWARD = 2, KER_FWD_SPEC = 3, KER_FWD_APPLY = 4, KER_AL_UPDATE = 5, KER_BACKWARD_SI = 6, KER_KP_DERIVS = 7 };
+//     KER_KP_DERIVS = l_x, l_xx at the keypoint steps (FK + Jacobian), one lane per (instance, keypoint), feeding every sweep (launch_solver)
+enum { KER_INIT = 0, KER_BACKWARD = 1, KER_FORWARD = 2, KER_FWD_SPEC = 3, KER_FWD_APPLY = 4, KER_AL_UPDATE = 5, KER_KP_DERIVS = 7 };
 
 void launch_solver(int kind, int nd, int which, bool al, const Bufs& a, int B, hipStream_t st, const FwdArgs& f);
 bool backward_si_supported(int kind, int nd, bool al, int m, int per_step, bool con_state_only);
 void launch_solver_v2(int kind, int nd, int which, bool al, const Bufs& a, int B, int T, hipStream_t st, const FwdArgs& f);
-void launch_backward_si_coop(bool al, const Bufs& a, int B, hipStream_t st);
+void launch_backward_si_coop(bool al, bool fused, const Bufs& a, int B, hipStream_t st, const SweepArgs& sw);
 bool backward_mfma_supported(int kind, int nd, bool al, int m);
 void launch_backward_mfma(int kind, int nd, bool al, const Bufs& a, int B, hipStream_t st);  // needs KER_KP_DERIVS first
-bool backward_gen_supported(int kind, int nd, bool al, int m);
-void launch_backward_gen(int kind, int nd, bool al, const Bufs& a, int B, hipStream_t st);  // needs KER_KP_DERIVS first
-bool forward_rows_supported(int kind, int nd, int n_alpha);
+bool forward_lin_supported(int kind, int nd, int n_alpha);
 void launch_apply_rows_tm(int kind, int nd, const Bufs& a, int B, hipStream_t st, const FwdArgs& f);  // time systems: re-roll of the winner, 8 lanes per instance
-void launch_forward_rows(int nd, int which, const Bufs& a, int B, hipStream_t st, const FwdArgs& f);
 void launch_forward_lin(int nd, int which, const Bufs& a, int B, int T, hipStream_t st, const FwdArgs& f);
 bool forward_wave_supported(int kind, int nd, int n_alpha);
 bool init_lti_supported(int kind, int nd);

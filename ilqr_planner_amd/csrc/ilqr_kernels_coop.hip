@@ -13,6 +13,15 @@
 // reciprocal of the NEXT pivot is formed by every lane from two extra broadcast reads while the current update is in
 // flight, which takes the reciprocal chain off the per-pivot critical path.
 // All exchange is wave-local: LDS operations of one wave execute in order, so there is no barrier anywhere.
+//
+// FUSED = true (the sweep follows k_forward_wg + k_select, ilqr_kernels_wave.hip): the acceptance of the previous iteration's line
+// search is folded into the sweep's load path instead of being a pass of its own (k_apply moved 190 MB per iteration that this
+// kernel re-read anyway).  Per step the vector lanes load xbar, ubar AND the alpha = 1 rollout x(1), u(1), form the accepted
+// trajectory x = xbar + alpha (x(1) - xbar) (the expression of k_apply, bit for bit), store it over x(1), and do the AL bookkeeping
+// of AL-ILQR.cpp:190,202-208 on it in registers: g = A x - b, I_k = penalty (g<0 && lambda==0 ? 0 : 1) with the multipliers
+// BEFORE the update, lambda_k = max(0, lambda_k + penalty' g) on update iterations -- the I_k buffer is neither written nor read.
+// At the end the instance's buffers flip.  Instances that stopped early but still have a pending acceptance run the same pass
+// (their gains are not stored).  The last iteration of a solve is finished by k_apply.
 #include <cstdlib>
 
 #include "ilqr_kernels.hpp"
@@ -44,8 +53,9 @@ __device__ __forceinline__ double oct_sum(double v) {  // sum over lanes 8m .. 8
     return v;
 }
 
-template <int MR, int LPI>
-__global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a) {
+template <int MR, bool FUSED>
+__global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a, SweepArgs sw) {
+    constexpr int LPI = 32;  // lanes per instance (8 and 16 measured slower at B = 4096: one wave per SIMD or less exposes the chain)
     constexpr int N = 7, IPW = 64 / LPI, EPL = (28 + LPI - 1) / LPI;
     constexpr int MRR = MR > 0 ? MR : 1;
     constexpr int ROWP = kd_rowp(N), RS = N * ROWP;
@@ -57,14 +67,25 @@ __global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a) {
     const int b = xcd_tile() * IPW + g;
     const int Bp = d.Bp, T = d.T;
     const bool ok = (b < d.B) && a.active[b < d.B ? b : 0];
-    if (__ballot(ok ? 1 : 0) == 0ull) return;  // wave-uniform
-    const int bb = (b < d.B) ? b : 0;           // clamp so that every address stays valid; stores are guarded by `ok`
+    const int bb = (b < d.B) ? b : 0;           // clamp so that every address stays valid; stores are guarded by `ok` / `acc`
+    // FUSED: winner of the previous line search still to be applied (k_select), 0 = none (first iteration, or nothing ran)
+    const int pendw = (FUSED && b < d.B) ? a.pend[bb] : 0;
+    const bool acc = pendw > 0;
+    if (__ballot((ok || acc) ? 1 : 0) == 0ull) return;  // wave-uniform
 
     const bool isV = l < N;
     const int v = isV ? l : 0;
     const int cur = a.cur[bb];
     const double* X = a.X[cur];
     const double* U = a.U[cur];
+    // accepted trajectory x = xbar + alpha (x(1) - xbar): x(1) lives in the other buffer and is overwritten by x.  Without a pending
+    // acceptance both pointers read xbar (x(1) - xbar = 0 reproduces xbar exactly) and nothing is stored.
+    const double aacc = acc ? ldexp(1.0, -(pendw - 1)) : 1.0;
+    const bool blend = acc && pendw > 1;        // alpha = 1: the other buffer already holds the accepted trajectory
+    double* X1 = blend ? a.X[1 - cur] : a.X[cur];
+    double* U1 = blend ? a.U[1 - cur] : a.U[cur];
+    if (FUSED && acc && !blend) { X = a.X[1 - cur]; U = a.U[1 - cur]; X1 = a.X[1 - cur]; U1 = a.U[1 - cur]; }
+    const bool upd = FUSED && acc && sw.do_update_prev;  // multiplier update of the iteration whose acceptance is applied here
     const double dt = d.dt, idt = 1.0 / dt, idt2 = idt * idt, reg = d.reg, dt2 = dt * dt;
     const double Rv = d.R_diag[v], Dv = Rv + reg;
     const int lim_on = d.limits_set;
@@ -121,7 +142,12 @@ __global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a) {
     double P[EPL], p = 0;
     UNR for (int e = 0; e < EPL; e++) P[e] = 0;
     {
-        const double xv = AT(X, (T - 1) * N + v, bb);
+        double xv = AT(X, (T - 1) * N + v, bb);
+        if (FUSED) {
+            const double x1 = AT(X1, (T - 1) * N + v, bb);
+            xv = fma(aacc, x1 - xv, xv);
+            if (blend && isV) AT(X1, (T - 1) * N + v, bb) = xv;
+        }
         if (kp_next == T - 1) {
             const double* src = a.kpd + (size_t)kpi * kpd_stride;
             UNR for (int e = 0; e < EPL; e++) P[e] = AT(src, N + ei[e] * N + ej[e], bb);
@@ -130,7 +156,8 @@ __global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a) {
             kp_next = (kpi >= 0) ? d.kp_t[kpi] : -1;
         } else if (lim_on) {
             UNR for (int e = 0; e < EPL; e++) {
-                const double xi = AT(X, (T - 1) * N + ei[e], bb);
+                double xi = AT(X, (T - 1) * N + ei[e], bb);
+                if (FUSED) xi = fma(aacc, AT(X1, (T - 1) * N + ei[e], bb) - xi, xi);
                 if (dg[e] && lw_i[e] != 0 && (xi > smax_i[e] || xi < smin_i[e])) P[e] = pen_xx;
             }
             if (lw_v != 0) {
@@ -144,9 +171,11 @@ __global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a) {
     constexpr int PF = 4;
     const double* Xp = X + (size_t)v * Bp + bb + (size_t)(T - 2) * Vstep;
     const double* Up = U + (size_t)v * Bp + bb + (size_t)(T - 2) * Vstep;
-    const double* Lp = a.lambda + bb + (size_t)(T - 2) * Lstep;
+    double* X1p = X1 + (size_t)v * Bp + bb + (size_t)(T - 2) * Vstep;
+    double* U1p = U1 + (size_t)v * Bp + bb + (size_t)(T - 2) * Vstep;
+    double* Lp = a.lambda + bb + (size_t)(T - 2) * Lstep;
     const double* Ip = a.Is + bb + (size_t)(T - 2) * Lstep;
-    double xr[PF], ur[PF], lr[PF][MRR], ir[PF][MRR];
+    double xr[PF], ur[PF], x1r[PF], u1r[PF], lr[PF][MRR], ir[PF][MRR];
     // Every load of the ring is unconditional and the unrolled group has no early exit: a CFG path that skips a fetch makes
     // the waitcnt pass fall back to vmcnt(0), which also waits for the previous step's gain stores.  Rows r >= m re-read row 0
     // (never used); steps below 0 re-read step 0 (the pointers stop there) and their work is skipped.
@@ -155,22 +184,36 @@ __global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a) {
     auto fetch = [&](int slot, int kk) {  // loads of timestep max(kk, 0) into ring slot
         xr[slot] = *Xp;
         ur[slot] = *Up;
+        x1r[slot] = u1r[slot] = 0;
+        if (FUSED) { x1r[slot] = *X1p; u1r[slot] = *U1p; }
         UNR for (int r = 0; r < MRR; r++) {
             lr[slot][r] = ir[slot][r] = 0;
-            if (MR > 0) { lr[slot][r] = Lp[rofs[r]]; ir[slot][r] = Ip[rofs[r]]; }
+            if (MR > 0) { lr[slot][r] = Lp[rofs[r]]; if (!FUSED) ir[slot][r] = Ip[rofs[r]]; }
         }
-        if (kk > 0) { Xp -= Vstep; Up -= Vstep; Lp -= Lstep; Ip -= Lstep; }  // uniform; no load inside the branch
+        if (kk > 0) { Xp -= Vstep; Up -= Vstep; Lp -= Lstep; Ip -= Lstep; if (FUSED) { X1p -= Vstep; U1p -= Vstep; } }  // uniform; no load inside the branch
     };
     UNR for (int q = 0; q < PF; q++) { fetch(q, T - 2 - q); __builtin_amdgcn_sched_barrier(0); }  // keep issue order (vmcnt)
+    // store side of the fused acceptance: the accepted x, u of step k go where x(1), u(1) were read (PF steps behind the loads)
+    double* Xw = X1 + (size_t)v * Bp + bb + (size_t)(T - 2) * Vstep;
+    double* Uw = U1 + (size_t)v * Bp + bb + (size_t)(T - 2) * Vstep;
+    double* Lw = a.lambda + bb + (size_t)(T - 2) * Lstep;
 
     for (int k0 = T - 2; k0 >= 0; k0 -= PF) {
       UNR for (int jj = 0; jj < PF; jj++) {
         const int k = k0 - jj;
-        const double xv = xr[jj], uv = ur[jj];
+        double xv = xr[jj], uv = ur[jj];
+        if (FUSED) {  // accepted trajectory (k_apply's expression)
+            xv = fma(aacc, x1r[jj] - xv, xv);
+            uv = fma(aacc, u1r[jj] - uv, uv);
+        }
         double lam[MRR], Isk[MRR];
         UNR for (int r = 0; r < MRR; r++) { lam[r] = lr[jj][r]; Isk[r] = ir[jj][r]; }
         fetch(jj, k - PF);
         if (k < 0) continue;  // uniform: dummy step of the last group
+        if (FUSED) {
+            if (blend && isV) { *Xw = xv; *Uw = uv; }
+            Xw -= Vstep; Uw -= Vstep;
+        }
         // ---- vectors in: x, Qu = R u + dt p
         const double Qu = Rv * uv + dt * p;
         if (isV) { sV[g][0][v] = xv; sV[g][1][v] = Qu; }
@@ -285,6 +328,16 @@ __global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a) {
                     } else {
                         UNR for (int q = 0; q < N; q++) gr += Arow[rr][q] * sV[g][0][q];
                     }
+                    if (FUSED) {  // AL-ILQR.cpp:190 (mask with the multipliers before the update), :202-208 (update)
+                        // gr is the constraint value only in the instance's first 8 lanes (oct_sum): lane 0's test is taken for all 32
+                        const unsigned long long fb = __ballot((gr < 0 && lam[rr] == 0) ? 1 : 0);
+                        Isk[rr] = sw.pen_in * (((fb >> (g * LPI)) & 1ull) ? 0.0 : 1.0);
+                        if (upd) {
+                            const double nv = lam[rr] + sw.pen_update_prev * gr;
+                            lam[rr] = nv > 0 ? nv : 0;
+                            if (l == 0) Lw[rofs[rr]] = lam[rr];
+                        }
+                    }
                     UNR for (int e = 0; e < EPL; e++) lxx[e] += Ai[rr][e] * Isk[rr] * Aj[rr][e];
                     lx += Av[rr] * (lam[rr] + Isk[rr] * gr);
                 }
@@ -296,25 +349,27 @@ __global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a) {
             P[e] = lxx[e] + t1 * idt2;
         }
         p = lx + p - (Qu + Dv * dv) * idt - reg * (Dv * Md - dv) * idt;
+        if (FUSED && MR > 0) Lw -= Lstep;
         LDS_ORDER();
       }
     }
+    if (FUSED && acc && l == 0) {  // the acceptance is complete: the other buffer is the instance's trajectory now
+        a.cur[bb] = 1 - cur;
+        a.pend[bb] = 0;
+    }
 }
 
-template <int LPI>
-static void launch_coop(bool al, const Bufs& a, int B, hipStream_t st) {
-    constexpr int IPW = 64 / LPI;
-    const dim3 grid(grid_x8((B + IPW - 1) / IPW)), block(64);
-    if (!al || a.m == 0) hipLaunchKernelGGL((k_backward_si_coop<0, LPI>), grid, block, 0, st, a);
-    else if (a.m <= 1) hipLaunchKernelGGL((k_backward_si_coop<1, LPI>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((k_backward_si_coop<4, LPI>), grid, block, 0, st, a);
+template <bool FUSED>
+static void launch_coop(bool al, const Bufs& a, int B, hipStream_t st, const SweepArgs& sw) {
+    const dim3 grid(grid_x8((B + 1) / 2)), block(64);  // two instances per single-wave workgroup
+    if (!al || a.m == 0) hipLaunchKernelGGL((k_backward_si_coop<0, FUSED>), grid, block, 0, st, a, sw);
+    else if (a.m <= 1) hipLaunchKernelGGL((k_backward_si_coop<1, FUSED>), grid, block, 0, st, a, sw);
+    else hipLaunchKernelGGL((k_backward_si_coop<4, FUSED>), grid, block, 0, st, a, sw);
 }
 
-void launch_backward_si_coop(bool al, const Bufs& a, int B, hipStream_t st) {
-    static const int lpi = std::getenv("ILQR_BWD_LPI") ? std::atoi(std::getenv("ILQR_BWD_LPI")) : 32;  // lanes per instance
-    if (lpi == 32) launch_coop<32>(al, a, B, st);
-    else if (lpi == 8) launch_coop<8>(al, a, B, st);
-    else launch_coop<16>(al, a, B, st);
+void launch_backward_si_coop(bool al, bool fused, const Bufs& a, int B, hipStream_t st, const SweepArgs& sw) {
+    if (fused) launch_coop<true>(al, a, B, st, sw);
+    else launch_coop<false>(al, a, B, st, sw);
 }
 
 }  // namespace ilqr

@@ -354,9 +354,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 }
 
 bool backward_mfma_supported(int kind, int nd, bool al, int m) {
-    static const bool off = std::getenv("ILQR_BWD") && (!std::strcmp(std::getenv("ILQR_BWD"), "v1") || !std::strcmp(std::getenv("ILQR_BWD"), "gen"));
     (void)nd;
-    return !off && kind != 2 && (!al || m <= 16);
+    return kind != 2 && (!al || m <= 16);
 }
 
 template <class S>

@@ -1,17 +1,8 @@
-// ilqr_kernels_rows.hip -- row-parallel forward pass / line search for the PosOrn systems (gfx950, fp64).
-//
-// The line search of ILQRRecursive.cpp:101-155 as two lean passes over the gains:
-//   COST pass   all n_alpha step sizes of an instance at once, costs only.  8 lanes per instance, lane r owns control row
-//               r: its gain row K_k[r,:], d_k[r], xbar_k[r], ubar_k[r] stream straight from HBM into that lane's registers
-//               (4-step prefetch ring, no staging), and it carries x_r(alpha) for every alpha.  The only exchange per
-//               timestep is the all-gather of dx(alpha) = x(alpha) - xbar through LDS; the K row is reused across all
-//               alphas, so the pass issues ~4x fewer instructions per instance-step than one lane group per alpha.
-//               Single-integrator / double-integrator dynamics make the state update local to the lane
-//               (x_r += dt u_r).  Keypoint costs (FK) are evaluated by lane (alpha mod 8) from the gathered state.
-//               The winner is the first alpha whose cost is below cost0 and not NaN, else the last one -- exactly
-//               what the reference's do/while would have settled on.
-//   APPLY pass  re-rolls the winning alpha (1 alpha, same lane mapping), writes X, U into the instance's inactive
-//               trajectory buffer, accumulates sum_k ||du_k|| for the early-stop test, flips the buffer.
+// ilqr_kernels_rows.hip -- 8 lanes per instance, lane r owns control row r (gfx950, fp64):
+//   k_forward_lin (+ k_blend, k_flip)   linear line search of the 2nd-order PosOrn system (ILQRRecursive.cpp:101-155)
+//   k_apply_rows_tm                     time systems: re-roll of the accepted step size where the speculated one lost
+// A lane's gain row K_k[r,:], d_k[r], xbar_k[r], ubar_k[r] stream straight from HBM into its registers (4-step prefetch ring, no
+// staging); the only exchange per timestep is the all-gather of the state deviation through LDS.
 // Workgroup = one wave = 8 instances: all exchange is wave-local (LDS operations of a wave execute in order), no barrier.
 #include "ilqr_kernels.hpp"
 #include "ilqr_step.hpp"
@@ -19,245 +10,6 @@
 namespace ilqr {
 
 #define LDS_ORDER() asm volatile("" ::: "memory")
-
-template <class S, int NA, bool APPLY>
-__global__ __launch_bounds__(64) void k_forward_rows(Bufs a, FwdArgs f) {
-    static_assert(S::KIND == 0, "row-parallel forward: PosOrn systems only (the time systems' dt couples the rows)");
-    constexpr int NX = S::NX, NU = S::NU, ND = S::ND, NK = NU * NX;
-    constexpr int NXP = (NX + 1) & ~1;            // dx row padded to an even number of doubles (16-B rows)
-    constexpr int DXS = NA * NXP + 2;             // per-instance stride (doubles), +16 B to spread the 8 instances over banks
-    constexpr int XUP = ((NX + NU) + 1) & ~1;
-    constexpr int XUS = NA * XUP + 2;
-    constexpr int ROWP = kd_rowp(NX), RS = NU * ROWP;
-    constexpr int NLD = ROWP + ND + 1;            // doubles fetched per lane per step: gain row {K row, d, pad} | xbar (q, dq) | ubar
-    constexpr int PF = 4;
-    __shared__ __attribute__((aligned(16))) double sDX[8 * DXS];
-    __shared__ __attribute__((aligned(16))) double sXU[APPLY ? 8 * 8 : 8 * XUS];  // COST: gathered (x, u) per alpha at keypoint steps; APPLY: du^2 per row
-    __shared__ double sP[8][8][NA];
-    __shared__ double sKc[8][NA];
-
-    const DevDesc& d = *a.desc;
-    const int lane = threadIdx.x, g = lane >> 3, r0 = lane & 7;
-    const int b = xcd_tile() * 8 + g;
-    const int Bp = d.Bp, T = d.T, B = d.B;
-    const bool inst_ok = (b < B) && (APPLY ? (a.pend[b < B ? b : 0] > 0) : (a.active[b < B ? b : 0] != 0));
-    if (__ballot(inst_ok ? 1 : 0) == 0ull) return;  // wave-uniform
-    const int bb = (b < B) ? b : 0;
-    const bool act = r0 < NU;             // lane 7 has no control row
-    const int r = act ? r0 : NU - 1;      // clamp: keeps every address valid, results of lane 7 are never used
-    const int n_alpha = APPLY ? 1 : (f.n_alpha < NA ? f.n_alpha : NA);
-
-    const double dt = d.dt, hdt2 = dt * dt / 2;
-    const int lim_on = d.limits_set;
-    const double pen = d.penalty;
-    double smax[ND], smin[ND];
-    int lw[ND];
-    UNR for (int q = 0; q < ND; q++) { smax[q] = d.smax[q * DOF + r]; smin[q] = d.smin[q * DOF + r]; lw[q] = d.lw[q * DOF + r]; }
-    const int n_kp = d.n_kp;
-    int kpi = 0, kp_next = (n_kp > 0) ? d.kp_t[0] : -1;
-
-    double alpha[NA];
-    if (APPLY) alpha[0] = ldexp(1.0, -(a.pend[bb] - 1));
-    else { UNR for (int q = 0; q < NA; q++) alpha[q] = ldexp(1.0, -q); }
-
-    const int cur = a.cur[bb];
-    // running source pointers for this lane's row
-    const double* pK = a.KD + (size_t)bb * RS + r * ROWP;  // this lane's gain row {K[r][0..NX-1], d[r]}: 16-byte aligned, contiguous
-    const double* pX = a.X[cur] + (size_t)r * Bp + bb;
-    const double* pU = a.U[cur] + (size_t)r * Bp + bb;
-    const size_t sK_ = (size_t)Bp * RS, sU_ = (size_t)NU * Bp, sX_ = (size_t)NX * Bp;
-    double* oX = a.X[1 - cur] + (size_t)r * Bp + bb;
-    double* oU = a.U[1 - cur] + (size_t)r * Bp + bb;
-
-    double ring[PF][NLD];
-    // Unconditional loads: a load guarded by a branch makes the number of outstanding VMEM operations path-dependent and
-    // the compiler then waits with vmcnt(0), i.e. for the prefetches it has just issued.  Past the end of the horizon
-    // the pointers simply stop advancing (the last timestep is fetched again and never used).
-    auto fetch = [&](int slot, int k) {
-        UNR for (int q = 0; q < ROWP / 2; q++) {  // 16-byte loads
-            const double2 v2 = reinterpret_cast<const double2*>(pK)[q];
-            ring[slot][2 * q] = v2.x;
-            ring[slot][2 * q + 1] = v2.y;
-        }
-        UNR for (int q = 0; q < ND; q++) ring[slot][ROWP + q] = pX[(size_t)(q * DOF) * Bp];
-        ring[slot][ROWP + ND] = *pU;
-        const size_t adv = (k < T - 2) ? 1 : 0;  // uniform
-        pK += adv * sK_; pX += adv * sX_; pU += adv * sU_;
-    };
-    // sched_barrier: the scheduler must not reorder the preamble's loads -- if slot 0 is issued last, the waitcnt pass merges
-    // "distance 0" into the loop header and every NS-th step drains the whole queue (vmcnt(6) instead of vmcnt(6 PF))
-    UNR for (int q = 0; q < PF; q++) { fetch(q, q); __builtin_amdgcn_sched_barrier(0); }
-
-    // state of this lane's coordinate(s) for every alpha
-    double xq[NA], xd[NA], pc[NA];
-    const double q0 = AT(a.q0, r, bb), dq0 = (ND == 2) ? AT(a.dq0, r, bb) : 0.0;
-    UNR for (int al = 0; al < NA; al++) { xq[al] = q0; xd[al] = dq0; pc[al] = 0; }
-    double kpc0 = 0, kpc1 = 0, dun = 0;
-
-    double* myDX = sDX + g * DXS;
-    double* myXU = sXU + (APPLY ? g * 8 : g * XUS);
-
-    auto limit_cost_of = [&](double v, int q) -> double {  // inspectJointLimit on one coordinate
-        double qv = 0, L = 0;
-        if (lw[q] != 0) {
-            if (v > smax[q]) { qv = smax[q] - v; L = pen; }
-            else if (v < smin[q]) { qv = smin[q] - v; L = pen; }
-        }
-        return qv * L * qv;
-    };
-    // keypoint cost of alpha index `al` from the gathered state (u may be null: terminal cost)
-    auto kp_eval = [&](int al, bool with_u) -> double {
-        double xt[NX], ut[NU];
-        UNR for (int jx = 0; jx < NX; jx++) xt[jx] = myXU[al * XUP + jx];
-        UNR for (int ju = 0; ju < NU; ju++) ut[ju] = with_u ? myXU[al * XUP + NX + ju] : 0.0;
-        return kp_cost_call<S>(&d, a.kp_tg, Bp, bb, kpi, xt, ut);
-    };
-
-    const int nsteps = T - 1;
-    for (int k0 = 0; k0 < nsteps; k0 += PF) {
-        UNR for (int jj = 0; jj < PF; jj++) {
-            const int k = k0 + jj;
-            double Kr[NX];
-            UNR for (int jx = 0; jx < NX; jx++) Kr[jx] = ring[jj][jx];
-            const double dr = ring[jj][NX], ub = ring[jj][ROWP + ND];
-            double xb[ND];
-            UNR for (int q = 0; q < ND; q++) xb[q] = ring[jj][ROWP + q];
-            fetch(jj, k + PF);
-            if (k >= nsteps) continue;  // uniform; dummy step of the last group: the fetch is issued, the work skipped (see k_forward_lin)
-            // ---- all-gather of dx(alpha)
-            if (act) {
-                UNR for (int al = 0; al < NA; al++) {
-                    myDX[al * NXP + r] = xq[al] - xb[0];
-                    if (ND == 2) myDX[al * NXP + DOF + r] = xd[al] - xb[1];
-                }
-            }
-            LDS_ORDER();
-            double u[NA];
-            UNR for (int al = 0; al < NA; al++) {
-                double s0 = 0, s1 = 0;
-                UNR for (int jx = 0; jx < NX; jx += 2) s0 += Kr[jx] * myDX[al * NXP + jx];
-                UNR for (int jx = 1; jx < NX; jx += 2) s1 += Kr[jx] * myDX[al * NXP + jx];
-                const double du = (s0 + s1) + alpha[al] * dr;
-                u[al] = ub + du;
-                if (APPLY && f.early_stop) {  // ||du_k||: sum over the 7 rows through LDS (only the early-stop test needs it)
-                    LDS_ORDER();
-                    if (act) myXU[r] = du * du;
-                    LDS_ORDER();
-                    double n2 = 0;
-                    UNR for (int ju = 0; ju < NU; ju++) n2 += myXU[ju];
-                    dun += sqrt(n2);
-                    LDS_ORDER();
-                }
-            }
-            if (APPLY) {
-                if (inst_ok && act) {
-                    *oX = xq[0];
-                    if (ND == 2) oX[(size_t)DOF * Bp] = xd[0];
-                    *oU = u[0];
-                }
-                oX += sX_;
-                oU += sU_;
-            } else {
-                // ---- stage cost l(x_k, u_k, k): limits on this lane's coordinates, task cost at keypoint steps
-                if (lim_on) {
-                    UNR for (int al = 0; al < NA; al++) {
-                        pc[al] += limit_cost_of(xq[al], 0);
-                        if (ND == 2) pc[al] += limit_cost_of(xd[al], 1);
-                    }
-                }
-                if (k == kp_next) {  // uniform, rare
-                    if (act) {
-                        UNR for (int al = 0; al < NA; al++) {
-                            myXU[al * XUP + r] = xq[al];
-                            if (ND == 2) myXU[al * XUP + DOF + r] = xd[al];
-                            myXU[al * XUP + NX + r] = u[al];
-                        }
-                    }
-                    LDS_ORDER();
-                    if (r0 < n_alpha) kpc0 += kp_eval(r0, true);
-                    if (NA > 8 && r0 + 8 < n_alpha) kpc1 += kp_eval(r0 + 8, true);
-                    LDS_ORDER();
-                    kpi++;
-                    kp_next = (kpi < n_kp) ? d.kp_t[kpi] : -1;
-                }
-            }
-            // ---- dynamics (SimulationInterface.cpp:19-31), local to the lane
-            UNR for (int al = 0; al < NA; al++) {
-                if (ND == 1) {
-                    xq[al] = xq[al] + (dt * u[al] + dt * dt / 2 * 0.0);
-                } else {
-                    const double vv = xd[al];
-                    xq[al] = xq[al] + (dt * vv + hdt2 * u[al]);
-                    xd[al] = vv + dt * u[al];
-                }
-            }
-            LDS_ORDER();
-        }
-    }
-
-    if (APPLY) {
-        if (inst_ok && act) {  // x_{T-1}
-            *oX = xq[0];
-            if (ND == 2) oX[(size_t)DOF * Bp] = xd[0];
-        }
-        if (inst_ok && r0 == 0) {
-            const double al_ = alpha[0], c = a.cost[bb];
-            a.cur[bb] = 1 - cur;
-            a.pend[bb] = 0;
-            bool stop = f.early_stop && (al_ * sqrt(dun) < d.stop_tol);
-            if (!f.al) stop = stop && (c < 1e-3);  // ILQRRecursive.cpp:174 vs AL-ILQR.cpp:225
-            if (stop) a.active[bb] = 0;
-        }
-        return;
-    }
-    // ---- terminal cost l_F(x_{T-1}) = l(x_{T-1}, 0, T-1)
-    if (lim_on) {
-        UNR for (int al = 0; al < NA; al++) {
-            pc[al] += limit_cost_of(xq[al], 0);
-            if (ND == 2) pc[al] += limit_cost_of(xd[al], 1);
-        }
-    }
-    if (kp_next == T - 1) {
-        if (act) {
-            UNR for (int al = 0; al < NA; al++) {
-                myXU[al * XUP + r] = xq[al];
-                if (ND == 2) myXU[al * XUP + DOF + r] = xd[al];
-            }
-        }
-        LDS_ORDER();
-        if (r0 < n_alpha) kpc0 += kp_eval(r0, false);
-        if (NA > 8 && r0 + 8 < n_alpha) kpc1 += kp_eval(r0 + 8, false);
-        LDS_ORDER();
-    }
-    // ---- total cost per alpha, winner, bookkeeping (lane 0 of each instance)
-    UNR for (int al = 0; al < NA; al++) sP[g][r0][al] = act ? pc[al] : 0.0;
-    if (r0 < NA) sKc[g][r0] = kpc0;
-    if (NA > 8 && r0 + 8 < NA) sKc[g][r0 + 8] = kpc1;
-    LDS_ORDER();
-    if (inst_ok && r0 == 0) {
-        const double cost0 = a.cost[bb];
-        int w = n_alpha - 1;
-        double wcost = 0;
-        bool found = false;
-        UNR for (int al = 0; al < NA; al++) {
-            double c = sKc[g][al];
-            UNR for (int q = 0; q < 8; q++) c += sP[g][q][al];
-            const bool okc = (al < n_alpha) && !((c >= cost0) || isnan(c));
-            if (!found && (okc || al == n_alpha - 1)) { w = al; wcost = c; found = true; }
-        }
-        const double walpha = ldexp(1.0, -w);
-        a.cost[bb] = wcost;
-        a.alpha[bb] = walpha;
-        a.iters[bb] = f.it + 1;
-        a.status[bb] = (isfinite(wcost) ? 0 : 1) | ((walpha <= d.alpha_floor) ? 2 : 0);
-        if (a.cost_trace) {
-            a.cost_trace[(size_t)f.it * Bp + bb] = wcost;
-            a.alpha_trace[(size_t)f.it * Bp + bb] = walpha;
-        }
-        a.pend[bb] = w + 1;  // the APPLY pass writes the accepted trajectory and decides the early stop
-        a.pred[bb] = w;
-    }
-}
 
 // ------------------------------------------------------------------------------------------------ linear line search
 //
@@ -651,23 +403,11 @@ static void launch_lin_sys(const Bufs& a, int B, int T, hipStream_t st, const Fw
     }
 }
 
-void launch_forward_lin(int nd, int which, const Bufs& a, int B, int T, hipStream_t st, const FwdArgs& f) {
-    if (nd == 1) launch_lin_sys<Sys<0, 1>>(a, B, T, st, f, which);
-    else launch_lin_sys<Sys<0, 2>>(a, B, T, st, f, which);
-}
+bool forward_lin_supported(int kind, int nd, int n_alpha) { return kind == 0 && nd == 2 && n_alpha <= 16; }  // (PosOrn-1: k_forward_wg)
 
-template <class S>
-static void launch_rows_sys(int which, const Bufs& a, int B, hipStream_t st, const FwdArgs& f) {
-    const dim3 grid(grid_x8((B + 7) / 8)), block(64);
-    if (which == KER_FWD_APPLY) {
-        hipLaunchKernelGGL((k_forward_rows<S, 1, true>), grid, block, 0, st, a, f);
-    } else if (f.n_alpha <= 1) {
-        hipLaunchKernelGGL((k_forward_rows<S, 1, false>), grid, block, 0, st, a, f);
-    } else if (f.n_alpha <= 11) {
-        hipLaunchKernelGGL((k_forward_rows<S, 11, false>), grid, block, 0, st, a, f);
-    } else {
-        hipLaunchKernelGGL((k_forward_rows<S, 16, false>), grid, block, 0, st, a, f);
-    }
+void launch_forward_lin(int nd, int which, const Bufs& a, int B, int T, hipStream_t st, const FwdArgs& f) {
+    (void)nd;
+    launch_lin_sys<Sys<0, 2>>(a, B, T, st, f, which);
 }
 
 void launch_apply_rows_tm(int kind, int nd, const Bufs& a, int B, hipStream_t st, const FwdArgs& f) {
@@ -675,13 +415,6 @@ void launch_apply_rows_tm(int kind, int nd, const Bufs& a, int B, hipStream_t st
     if (kind == 3) hipLaunchKernelGGL((k_apply_rows_tm<Sys<3, 1>>), grid, block, 0, st, a, f);
     else if (nd == 1) hipLaunchKernelGGL((k_apply_rows_tm<Sys<1, 1>>), grid, block, 0, st, a, f);
     else hipLaunchKernelGGL((k_apply_rows_tm<Sys<1, 2>>), grid, block, 0, st, a, f);
-}
-
-bool forward_rows_supported(int kind, int nd, int n_alpha) { return kind == 0 && (nd == 1 || nd == 2) && n_alpha <= 16; }
-
-void launch_forward_rows(int nd, int which, const Bufs& a, int B, hipStream_t st, const FwdArgs& f) {
-    if (nd == 1) launch_rows_sys<Sys<0, 1>>(which, a, B, st, f);
-    else launch_rows_sys<Sys<0, 2>>(which, a, B, st, f);
 }
 
 }  // namespace ilqr

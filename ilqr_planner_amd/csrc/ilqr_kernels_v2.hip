@@ -359,280 +359,41 @@ __global__ __launch_bounds__(256) void k_al_post(Bufs a, FwdArgs f) {
     }
 }
 
-// l_x, l_xx of the keypoint steps (System::cost_x / cost_xx incl. the limit terms) for the current trajectory, one lane per
-// (instance, keypoint).  Keeps FK, the quaternion log map and J'QJ out of the sequential sweep: the sweep only loads
-// NX + NX*NX doubles at the (two) keypoint steps.
-template <class S, bool EXT>
-__global__ __launch_bounds__(64) void k_kp_derivs(Bufs a) {
-    constexpr int NX = S::NX;
-    const DevDesc& d = *a.desc;
-    const int b = blockIdx.x * 64 + threadIdx.x;
-    const int kpi = blockIdx.y;
-    if (b >= d.B) return;
-    if (!a.active[b]) return;
-    const int Bp = d.Bp;
-    const int k = d.kp_t[kpi];
-    const double* X = a.X[a.cur[b]];
-    double x[NX], lxx[NX][NX], lx[NX];
-    UNR for (int i = 0; i < NX; i++) x[i] = AT(X, k * NX + i, b);
-    stage_derivs<S, true, EXT>(d, a, b, x, kpi, lxx, lx);
-    double* out = a.kpd + (size_t)kpi * (NX + NX * NX) * Bp;
-    UNR for (int i = 0; i < NX; i++) {
-        AT(out, i, b) = lx[i];
-        UNR for (int j = 0; j < NX; j++) AT(out, NX + i * NX + j, b) = lxx[i][j];
-    }
-}
-
-// ------------------------------------------------------------------------------------------------ backward, closed form
-
-__device__ __forceinline__ constexpr int sym(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
-
-// AL rows must not touch the controls for the closed form (checked on the host); they then only add to l_x, l_xx.
-// MR = constraint rows kept in registers (m <= MR and per_step == 0), 0 = no AL.
-template <int MR>
-__global__ __launch_bounds__(64) void k_backward_si(Bufs a) {
-    using S = Sys<0, 1>;
-    constexpr int N = 7, NS = N * (N + 1) / 2;
-    constexpr int MRR = MR > 0 ? MR : 1;
-    const DevDesc& d = *a.desc;
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= d.B) return;
-    if (!a.active[b]) return;
-    const int Bp = d.Bp, T = d.T;
-    const int cur = a.cur[b];
-    const double* X = a.X[cur];
-    const double* U = a.U[cur];
-    double* KDp = a.KD;
-    constexpr int ROWP = kd_rowp(N), RS = N * ROWP;
-    const double dt = d.dt, idt = 1.0 / dt, idt2 = idt * idt, reg = d.reg;
-    double Dg[N], Rd[N];
-    UNR for (int i = 0; i < N; i++) { Rd[i] = d.R_diag[i]; Dg[i] = Rd[i] + reg; }
-    LimRegs<N> lim;
-    lim.load(d);
-    // constraint rows (state part) and right-hand sides
-    const int m = a.m;
-    double Ax[MRR][N], bb[MRR];
-    UNR for (int r = 0; r < MRR; r++) {
-        bb[r] = 0;
-        UNR for (int i = 0; i < N; i++) Ax[r][i] = 0;
-        if (MR > 0 && r < m) {
-            bb[r] = a.conb[r];
-            UNR for (int i = 0; i < N; i++) Ax[r][i] = a.conA[(size_t)r * 2 * N + i];
-        }
-    }
-    const double* lamp = a.lambda;
-    const double* Isp = a.Is;
-
-    double P[NS], p[N], x[N], u[N];
-    int kpi = d.n_kp - 1;
-    int kp_next = (kpi >= 0) ? d.kp_t[kpi] : -1;
-    // terminal: P = l_xx(x_{T-1}), p = l_x(x_{T-1})   (no constraint on the final state, AL-ILQR.cpp:96)
-    const double* kpd = a.kpd;
-    {
-        UNR for (int i = 0; i < N; i++) x[i] = AT(X, (T - 1) * N + i, b);
-        UNR for (int i = 0; i < N; i++) p[i] = 0;
-        UNR for (int i = 0; i < NS; i++) P[i] = 0;
-        if (kp_next == T - 1) {  // l_x | l_xx precomputed by k_kp_derivs (incl. limits)
-            const double* src = kpd + (size_t)kpi * (N + N * N) * Bp;
-            UNR for (int i = 0; i < N; i++) {
-                p[i] = AT(src, i, b);
-                UNR for (int j = 0; j <= i; j++) P[sym(i, j)] = AT(src, N + i * N + j, b);
-            }
-            kpi--;
-            kp_next = (kpi >= 0) ? d.kp_t[kpi] : -1;
-        } else if (lim.on) {
-            UNR for (int i = 0; i < N; i++) {
-                if (lim.lw[i] != 0) {
-                    double qv = 0, L = 0;
-                    if (x[i] > lim.smax[i]) { qv = lim.smax[i] - x[i]; L = lim.penalty; }
-                    else if (x[i] < lim.smin[i]) { qv = lim.smin[i] - x[i]; L = lim.penalty; }
-                    p[i] += -L * qv;
-                    P[sym(i, i)] += (L != 0.0) ? lim.pen_xx : 0.0;
-                }
-            }
-        }
-    }
-    // one-step-ahead prefetch of xbar, ubar, lambda, I
-    double xn_[N], un_[N], lamn[MRR], Isn[MRR];
-    UNR for (int i = 0; i < N; i++) { xn_[i] = AT(X, (T - 2) * N + i, b); un_[i] = AT(U, (T - 2) * N + i, b); }
-    UNR for (int r = 0; r < MRR; r++) {
-        lamn[r] = 0; Isn[r] = 0;
-        if (MR > 0 && r < m) { lamn[r] = AT(lamp, (T - 2) * m + r, b); Isn[r] = AT(Isp, (T - 2) * m + r, b); }
-    }
-
-    for (int k = T - 2; k >= 0; k--) {
-        double lam[MRR], Isk[MRR];
-        UNR for (int i = 0; i < N; i++) { x[i] = xn_[i]; u[i] = un_[i]; }
-        UNR for (int r = 0; r < MRR; r++) { lam[r] = lamn[r]; Isk[r] = Isn[r]; }
-        if (k > 0) {
-            UNR for (int i = 0; i < N; i++) { xn_[i] = AT(X, (k - 1) * N + i, b); un_[i] = AT(U, (k - 1) * N + i, b); }
-            UNR for (int r = 0; r < MRR; r++)
-                if (MR > 0 && r < m) { lamn[r] = AT(lamp, (k - 1) * m + r, b); Isn[r] = AT(Isp, (k - 1) * m + r, b); }
-        }
-
-        // S = D + dt^2 P   (= Quu + reg I)
-        double Sm[NS];
-        UNR for (int i = 0; i < N; i++)
-            UNR for (int j = 0; j <= i; j++) Sm[sym(i, j)] = dt * (dt * P[sym(i, j)]) + ((i == j) ? Dg[i] : 0.0);
-        // LDL^T:  S = L diag(e) L^T  (L unit lower below the diagonal of Sm, e on its diagonal, ie = 1/e)
-        double ie[N];
-        UNR for (int j = 0; j < N; j++) {
-            double le[N];  // L_jq * e_q
-            double ej = Sm[sym(j, j)];
-            UNR for (int q = 0; q < j; q++) {
-                le[q] = Sm[sym(j, q)] * Sm[sym(q, q)];
-                ej -= Sm[sym(j, q)] * le[q];
-            }
-            Sm[sym(j, j)] = ej;
-            ie[j] = 1.0 / ej;
-            UNR for (int i = j + 1; i < N; i++) {
-                double s = Sm[sym(i, j)];
-                UNR for (int q = 0; q < j; q++) s -= Sm[sym(i, q)] * le[q];
-                Sm[sym(i, j)] = s * ie[j];
-            }
-        }
-        // Li = L^-1 (unit lower)
-        double Li[NS];
-        UNR for (int i = 0; i < N; i++) {
-            Li[sym(i, i)] = 1.0;
-            UNR for (int j = 0; j < i; j++) {
-                double s = Sm[sym(i, j)];
-                UNR for (int q = j + 1; q < i; q++) s += Sm[sym(i, q)] * Li[sym(q, j)];
-                Li[sym(i, j)] = -s;
-            }
-        }
-        // M = S^-1 = Li^T diag(1/e) Li  (symmetric)
-        double M[NS];
-        UNR for (int i = 0; i < N; i++) {
-            double ti[N];  // column i of diag(1/e) Li
-            UNR for (int q = i; q < N; q++) ti[q] = Li[sym(q, i)] * ie[q];
-            UNR for (int j = 0; j <= i; j++) {
-                double s = 0;
-                UNR for (int q = i; q < N; q++) s += ti[q] * Li[sym(q, j)];
-                M[sym(i, j)] = s;
-            }
-        }
-        // Qu = R u + dt p ; dv = -M Qu ; Md = M dv
-        double Qu[N], dv[N], Md[N];
-        UNR for (int i = 0; i < N; i++) Qu[i] = Rd[i] * u[i] + dt * p[i];
-        UNR for (int i = 0; i < N; i++) {
-            double s = 0;
-            UNR for (int j = 0; j < N; j++) s += M[sym(i, j)] * Qu[j];
-            dv[i] = -s;
-        }
-        UNR for (int i = 0; i < N; i++) {
-            double s = 0;
-            UNR for (int j = 0; j < N; j++) s += M[sym(i, j)] * dv[j];
-            Md[i] = s;
-        }
-        // K = (M D - I)/dt ; store K, d
-        UNR for (int i = 0; i < N; i++) {
-            UNR for (int j = 0; j < N; j++)
-                KD_REC(KDp, Bp, RS, k, b)[i * ROWP + j] = (M[sym(i, j)] * Dg[j] - ((i == j) ? 1.0 : 0.0)) * idt;
-            KD_REC(KDp, Bp, RS, k, b)[i * ROWP + N] = dv[i];
-        }
-        // stage derivatives (keypoint / limits / AL rows)
-        double lx[N];
-        UNR for (int i = 0; i < N; i++) lx[i] = 0;
-        double lxxs[NS];
-        UNR for (int i = 0; i < NS; i++) lxxs[i] = 0;
-        if (k == kp_next) {  // rare: l_x | l_xx precomputed by k_kp_derivs (incl. the limit terms)
-            const double* src = kpd + (size_t)kpi * (N + N * N) * Bp;
-            UNR for (int i = 0; i < N; i++) {
-                lx[i] = AT(src, i, b);
-                UNR for (int j = 0; j <= i; j++) lxxs[sym(i, j)] = AT(src, N + i * N + j, b);
-            }
-            kpi--;
-            kp_next = (kpi >= 0) ? d.kp_t[kpi] : -1;
-        } else if (lim.on) {
-            UNR for (int i = 0; i < N; i++) {
-                if (lim.lw[i] != 0) {
-                    double qv = 0, L = 0;
-                    if (x[i] > lim.smax[i]) { qv = lim.smax[i] - x[i]; L = lim.penalty; }
-                    else if (x[i] < lim.smin[i]) { qv = lim.smin[i] - x[i]; L = lim.penalty; }
-                    lx[i] += -L * qv;
-                    lxxs[sym(i, i)] += (L != 0.0) ? lim.pen_xx : 0.0;
-                }
-            }
-        }
-        if (MR > 0) {  // AL-ILQR.cpp:110-134 with c_u = 0: only Qxx, Qx change
-            UNR for (int r = 0; r < MRR; r++) {
-                if (r < m) {
-                    double g = 0;
-                    UNR for (int i = 0; i < N; i++) g += Ax[r][i] * x[i];
-                    g -= bb[r];
-                    const double wv = lam[r] + Isk[r] * g;
-                    UNR for (int i = 0; i < N; i++) {
-                        UNR for (int j = 0; j <= i; j++) lxxs[sym(i, j)] += Ax[r][i] * Isk[r] * Ax[r][j];
-                        lx[i] += Ax[r][i] * wv;
-                    }
-                }
-            }
-        }
-        // M2 = M M (symmetric) and the P, p updates
-        double Pn[NS];
-        UNR for (int i = 0; i < N; i++)
-            UNR for (int j = 0; j <= i; j++) {
-                double m2 = 0;
-                UNR for (int q = 0; q < N; q++) m2 += M[sym(i, q)] * M[sym(q, j)];
-                const double mij = M[sym(i, j)];
-                const double del = (i == j) ? 1.0 : 0.0;
-                const double t = del * Dg[i] - Dg[i] * mij * Dg[j] - reg * (Dg[i] * m2 * Dg[j] - Dg[i] * mij - mij * Dg[j] + del);
-                Pn[sym(i, j)] = lxxs[sym(i, j)] + t * idt2;
-            }
-        UNR for (int i = 0; i < N; i++) p[i] = lx[i] + p[i] - (Qu[i] + Dg[i] * dv[i]) * idt - reg * (Dg[i] * Md[i] - dv[i]) * idt;
-        UNR for (int i = 0; i < NS; i++) P[i] = Pn[i];
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ launchers
 
 template <class S>
-static void launch_v2_kernel(int which, const Bufs& a, int B, int T, hipStream_t st, const FwdArgs& f) {
+static void launch_tile(const Bufs& a, int B, hipStream_t st, const FwdArgs& f) {  // all step sizes of the time systems' line search + the decision
     const dim3 gridT(grid_x8((B + FT_TI - 1) / FT_TI)), blockT(FT_TI * 16);
-    switch (which) {
-        case KER_FWD_SPEC:
-            hipLaunchKernelGGL((k_forward_tile<S, false>), gridT, blockT, 0, st, a, f);
-            hipLaunchKernelGGL((k_select_x<S>), dim3((B + 3) / 4), dim3(64), 0, st, a, f);
-            break;
-        case KER_FWD_APPLY:
-            hipLaunchKernelGGL((k_forward_tile<S, true>), gridT, blockT, 0, st, a, f);
-            break;
-        case KER_AL_UPDATE:
-            hipLaunchKernelGGL((k_al_post<S>), dim3((B + 255) / 256, T - 1), dim3(256), 0, st, a, f);
-            break;
-        case KER_KP_DERIVS:
-            if (f.n_kp > 0 && f.kp_ext) hipLaunchKernelGGL((k_kp_derivs<S, true>), dim3((B + 63) / 64, f.n_kp), dim3(64), 0, st, a);
-            else if (f.n_kp > 0) hipLaunchKernelGGL((k_kp_derivs<S, false>), dim3((B + 63) / 64, f.n_kp), dim3(64), 0, st, a);
-            break;
-    }
+    hipLaunchKernelGGL((k_forward_tile<S, false>), gridT, blockT, 0, st, a, f);
+    hipLaunchKernelGGL((k_select_x<S>), dim3((B + 3) / 4), dim3(64), 0, st, a, f);
+}
+template <class S>
+static void launch_al_post(const Bufs& a, int B, int T, hipStream_t st, const FwdArgs& f) {
+    hipLaunchKernelGGL((k_al_post<S>), dim3((B + 255) / 256, T - 1), dim3(256), 0, st, a, f);
 }
 
-// closed-form sweep: usable for PosOrn nb_deriv=1 when no constraint row touches the controls, rows are shared over k
-// and there are at most 4 of them (they live in registers)
+// closed-form sweep (k_backward_si_coop): usable for single-integrator dynamics when no constraint row touches the controls, the rows
+// are shared over k and there are at most 4 of them (they live in registers)
 bool backward_si_supported(int kind, int nd, bool al, int m, int per_step, bool con_state_only) {
-    if (!((kind == 0 || kind == 2) && nd == 1)) return false;  // single-integrator dynamics: PosOrn-1 and JointSpace-1
+    if (!((kind == 0 || kind == 2) && nd == 1)) return false;  // PosOrn-1 and JointSpace-1
     if (!al) return true;
     return con_state_only && per_step == 0 && m <= 4;
 }
 
 void launch_solver_v2(int kind, int nd, int which, bool al, const Bufs& a, int B, int T, hipStream_t st, const FwdArgs& f) {
-    if (which == KER_BACKWARD_SI) {
-        static const bool lane_path = std::getenv("ILQR_BWD") && !std::strcmp(std::getenv("ILQR_BWD"), "lane");
-        if (!lane_path) { launch_backward_si_coop(al, a, B, st); return; }  // default: 32 lanes per instance
-        static const int bs = std::getenv("ILQR_BWD_BLOCK") ? std::atoi(std::getenv("ILQR_BWD_BLOCK")) : 64;  // lanes used per wave (experiment)
-        const dim3 grid((B + bs - 1) / bs), block(bs);
-        if (!al) hipLaunchKernelGGL((k_backward_si<0>), grid, block, 0, st, a);
-        else if (a.m <= 1) hipLaunchKernelGGL((k_backward_si<1>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((k_backward_si<4>), grid, block, 0, st, a);
-        return;
+    (void)al;
+    if (which == KER_FWD_SPEC) {  // time systems only (PosOrn: k_forward_wg / k_forward_lin)
+        if (kind == 3) launch_tile<Sys<3, 1>>(a, B, st, f);
+        else if (kind == 1 && nd == 1) launch_tile<Sys<1, 1>>(a, B, st, f);
+        else if (kind == 1) launch_tile<Sys<1, 2>>(a, B, st, f);
+    } else if (which == KER_AL_UPDATE) {
+        if (kind == 2) launch_al_post<Sys<2, 1>>(a, B, T, st, f);
+        else if (kind == 3) launch_al_post<Sys<3, 1>>(a, B, T, st, f);
+        else if (kind == 0 && nd == 1) launch_al_post<Sys<0, 1>>(a, B, T, st, f);
+        else if (kind == 0 && nd == 2) launch_al_post<Sys<0, 2>>(a, B, T, st, f);
+        else if (kind == 1 && nd == 1) launch_al_post<Sys<1, 1>>(a, B, T, st, f);
+        else launch_al_post<Sys<1, 2>>(a, B, T, st, f);
     }
-    if (kind == 2) launch_v2_kernel<Sys<2, 1>>(which, a, B, T, st, f);
-    else if (kind == 3) launch_v2_kernel<Sys<3, 1>>(which, a, B, T, st, f);
-    else if (kind == 0 && nd == 1) launch_v2_kernel<Sys<0, 1>>(which, a, B, T, st, f);
-    else if (kind == 0 && nd == 2) launch_v2_kernel<Sys<0, 2>>(which, a, B, T, st, f);
-    else if (kind == 1 && nd == 1) launch_v2_kernel<Sys<1, 1>>(which, a, B, T, st, f);
-    else launch_v2_kernel<Sys<1, 2>>(which, a, B, T, st, f);
 }
 
 }  // namespace ilqr

@@ -449,8 +449,7 @@ __global__ __launch_bounds__(64) void k_init_finish(Bufs a) {
 }
 
 bool init_lti_supported(int kind, int nd) {
-    static const bool off = std::getenv("ILQR_INIT") && !std::strcmp(std::getenv("ILQR_INIT"), "v1");
-    return !off && ((kind == 0 && (nd == 1 || nd == 2)) || (kind == 2 && nd == 1));
+    return (kind == 0 && (nd == 1 || nd == 2)) || (kind == 2 && nd == 1);
 }
 
 template <class S>
@@ -465,8 +464,7 @@ void launch_init_lti(int kind, int nd, const Bufs& a, int B, hipStream_t st) {
 }
 
 bool forward_wave_supported(int kind, int nd, int n_alpha) {
-    static const bool off = std::getenv("ILQR_FWD") && !std::strcmp(std::getenv("ILQR_FWD"), "lin");
-    return !off && (kind == 0 || kind == 2) && nd == 1 && n_alpha <= 16;
+    return (kind == 0 || kind == 2) && nd == 1 && n_alpha <= 16;
 }
 
 template <class S>

@@ -62,7 +62,30 @@ static __thread const double* g_lambda_mask = NULL;
 void orc_set_probe(orc_probe_rec* buf, int cap) { g_probe = buf; g_probe_cap = buf ? cap : 0; }
 void orc_set_resume(int it0, double init_penalty, const double* lambda_mask) { g_it0 = it0; g_init_penalty = init_penalty; g_lambda_mask = lambda_mask; }
 
+/* Test aid (variant bit 1): the inverse of a symmetric positive definite matrix by the symmetric sweep operator without pivoting --
+   another backward-stable algorithm for the same quantity.  Used only to measure how far an iteration's result depends on HOW Quu is
+   inverted (cond(Quu) * eps), never in the restated algorithm. */
+static int inverse_sweep_nopivot(int n, const double* A, double* Ainv) {
+    memcpy(Ainv, A, sizeof(double) * n * n);
+    for (int c = 0; c < n; c++) {
+        double d = Ainv[c * n + c];
+        if (d == 0.0) return 1;
+        for (int i = 0; i < n; i++) {
+            if (i == c) continue;
+            double f = Ainv[i * n + c] / d;
+            for (int j = 0; j < n; j++)
+                if (j != c) Ainv[i * n + j] -= f * Ainv[c * n + j];
+        }
+        for (int i = 0; i < n; i++)
+            if (i != c) { Ainv[i * n + c] = Ainv[i * n + c] / d; Ainv[c * n + i] = Ainv[c * n + i] / d; }
+        Ainv[c * n + c] = -1.0 / d;
+    }
+    for (int i = 0; i < n * n; i++) Ainv[i] = -Ainv[i];
+    return 0;
+}
+
 int orc_inverse(int n, const double* A, double* Ainv) {
+    if (g_variant & 2) return inverse_sweep_nopivot(n, A, Ainv);
     double* lu = (double*)malloc(sizeof(double) * n * n);
     int* piv = (int*)malloc(sizeof(int) * n);
     memcpy(lu, A, sizeof(double) * n * n);

@@ -15,16 +15,13 @@ namespace ilqr {
 }
 bool backward_si_supported(int, int, bool, int, int, bool) { return false; }
 bool backward_mfma_supported(int, int, bool, int) { return false; }
-bool backward_gen_supported(int, int, bool, int) { return false; }
-bool forward_rows_supported(int, int, int) { return false; }
+bool forward_lin_supported(int, int, int) { return false; }
 bool forward_wave_supported(int, int, int) { return false; }
 bool init_lti_supported(int, int) { return false; }
 void launch_solver_v2(int, int, int, bool, const Bufs&, int, int, hipStream_t, const FwdArgs&) { refuse("launch_solver_v2"); }
-void launch_backward_si_coop(bool, const Bufs&, int, hipStream_t) { refuse("k_backward_si_coop"); }
+void launch_backward_si_coop(bool, bool, const Bufs&, int, hipStream_t, const SweepArgs&) { refuse("k_backward_si_coop"); }
 void launch_backward_mfma(int, int, bool, const Bufs&, int, hipStream_t) { refuse("k_backward_mfma"); }
-void launch_backward_gen(int, int, bool, const Bufs&, int, hipStream_t) { refuse("k_backward_gen"); }
 void launch_apply_rows_tm(int, int, const Bufs&, int, hipStream_t, const FwdArgs&) { refuse("k_apply_rows_tm"); }
-void launch_forward_rows(int, int, const Bufs&, int, hipStream_t, const FwdArgs&) { refuse("k_forward_rows"); }
 void launch_forward_lin(int, int, const Bufs&, int, int, hipStream_t, const FwdArgs&) { refuse("k_forward_lin"); }
 void launch_init_lti(int, int, const Bufs&, int, hipStream_t) { refuse("k_init_roll_lti"); }
 void launch_forward_wave(int, const Bufs&, int, hipStream_t, const FwdArgs&) { refuse("k_forward_wg"); }
