@@ -7,10 +7,16 @@ PosOrn 1st-order System on the 7-DoF Panda chain, T=200, dt=0.05, B=4096 seeded 
 tutorial's inequality row (q_6 <= 2.0, penalty .25, scaling 1.1, multiplier update every 5 iterations), 20 iterations
 per solve, line search on, early stop off (fixed work).  A "step" = one such solve of the whole batch from U0.
 One problem-iteration = one backward Riccati sweep + one accepted forward rollout of one instance.
+`--config C4` (configs[3]: PosOrnTime 2nd order, 4096 instances per GPU -- 32768 over 8 GPUs) and `--config C5` (configs[4]:
+Batch-CP, T=400, B=8192) run the other BASELINE configurations through the same contract.
 
-N>1 (driver: torch.distributed.run, one rank per GPU): every rank solves its own 4096-instance shard (weak
-scaling, no data-path collective); the only exchange is the all-gather of the converged costs over RCCL, once per
-step, inside the timed region.
+N>1 (driver: torch.distributed.run, one rank per GPU): every rank solves its own shard (weak scaling, no data-path
+collective); the only exchange is the all-gather of the converged costs over RCCL (sharding.gather_costs), once per step,
+inside the timed region.  `--gather-trajectories` adds the gather of X / U (sharding.gather_trajectories).
+
+What is timed: `steps` solves between two fences (device synchronize + barrier + synchronize), per-launch profiling OFF, inputs
+resident in HBM.  Kernel durations for the roofline come from a SECOND pass with HIP events on the library's stream, after the
+timed region.  The oracle is used only for the `cpu_baseline` sample and the parity report (N = 1), never inside the timed region.
 """
 from __future__ import annotations
 
@@ -25,88 +31,142 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+METRIC = "iLQR iterations/sec (7-DoF, T=200, batch 4096) + final-cost rel-err vs Eigen ref"
 
 
-def pmc_traffic(category):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary (profiles/*_kernels.txt, two
-    separate passes: FETCH_SIZE, WRITE_SIZE; on gfx950 FETCH_SIZE counts half of a coalesced stream, so it is doubled --
-    MI355X_MICROARCH.md).  bench.py cannot run the profiler around itself; the summary is produced by
-    scripts/collect_profiles.sh with this same command.  Returns (bytes or None, source)."""
-    import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_kernels.txt")))
-    if not files:
+# ----------------------------------------------------------------------------- multi-rank plumbing (covered by tests/test_sharding_gloo.py)
+
+def fence(device_sync, dist=None):
+    """Both sides of the timed region: drain the device, meet the other ranks, drain again."""
+    device_sync()
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+    device_sync()
+
+
+def timed_region(step, steps, device_sync, dist=None):
+    """EXACTLY `steps` calls of step() between two fences; returns this rank's wall time in seconds."""
+    fence(device_sync, dist)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence(device_sync, dist)
+    return time.perf_counter() - t0
+
+
+def max_over_ranks(elapsed, dist=None, device="cpu"):
+    """MAX of the per-rank wall times (the job is as slow as its slowest shard)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(elapsed)
+    import torch
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_step(local_cost, total, local_X=None, local_U=None):
+    """The one exchange of a step: converged costs of all shards on every rank (and, on request, the trajectories on rank 0)."""
+    from ilqr_planner_amd import sharding
+
+    out = dict(cost=sharding.gather_costs(local_cost, total))
+    if local_X is not None:
+        out["X"] = sharding.gather_trajectories(local_X, total, dst=0)
+        out["U"] = sharding.gather_trajectories(local_U, total, dst=0)
+    return out
+
+
+# ----------------------------------------------------------------------------- roofline bookkeeping
+
+def pmc_traffic(config, category):
+    """HBM bytes per launch of a kernel category from the committed rocprofv3 --pmc summary of this round (profiles/r02_<config>_kernels.txt;
+    two separate passes FETCH_SIZE / WRITE_SIZE; on gfx950 FETCH_SIZE counts half of a coalesced stream and is doubled --
+    MI355X_MICROARCH.md).  bench.py cannot run the profiler around itself: the summary is produced by scripts/collect_profiles.sh with
+    this same command.  Returns (bytes or None, source)."""
+    f = os.path.join(ROOT, "profiles", f"r02_{config.lower()}_kernels.txt")
+    if not os.path.exists(f):
         return None, None
-    for f in reversed(files):  # newest summary that holds the counter passes for this kernel (summaries of other solvers have none)
-        fetch = write = None
-        for line in open(f):
-            if ("k_" + category) not in line:
-                continue
-            if "FETCH_SIZE" in line:
-                fetch = float(line.split("avg=")[1].split()[0]) * 1024 * 2
-            elif "WRITE_SIZE" in line:
-                write = float(line.split("avg=")[1].split()[0]) * 1024
-        if fetch is not None and write is not None:
-            return int(fetch + write), "profiles/" + os.path.basename(f)
-    return None, None
+    fetch = write = None
+    for line in open(f):
+        if not line.startswith(f"pmc[{category}]"):
+            continue
+        if "FETCH_SIZE" in line:
+            fetch = float(line.split("avg=")[1].split()[0]) * 1024 * 2
+        elif "WRITE_SIZE" in line:
+            write = float(line.split("avg=")[1].split()[0]) * 1024
+    if fetch is None or write is None:
+        return None, None
+    return int(fetch + write), "profiles/" + os.path.basename(f)
 
 
-def algorithmic_bytes(nx, nu, m, T, B):
-    """fp64 bytes one launch of each kernel must move if A_k, B_k are never stored (SURVEY.md 8d model):
-    backward: read x,u ; write K,d (+ read lambda, I_k for AL)
-    forward (per line-search trial): read K,d,x,u ; write x,u (+ write I_k, read lambda for AL)."""
+def algorithmic_bytes(cfg, nx, nu, m, B, fused):
+    """fp64 bytes one launch of each kernel category must move (SURVEY.md 8d model: A_k, B_k never stored).
+    Riccati solvers, per instance-step:  backward reads xbar, ubar (+ lambda, I_k) and writes K, d -- the fused sweep also reads x(1), u(1)
+    and writes the accepted x, u (the APPLY pass it replaces), and neither reads nor writes I_k;  forward = ONE pass over K, d, xbar, ubar
+    + write of x(1), u(1) whatever the number of step sizes.
+    Batch-CP in coefficient space, per instance and SOLVE: the horizon is walked by the first kernel (reads U0) and by the last two
+    (write U, X); an iteration touches keypoint-sized data only."""
+    T = cfg["T"]
+    if cfg["solver"] == "batch_cp":
+        return dict(rollout=8 * (T - 1) * nu * B, apply=8 * ((T - 1) * nu + T * nx) * B, backward=None, forward=None)
     steps = (T - 1) * B
-    bwd = 8 * ((nx + nu) + (nu * nx + nu) + 2 * m) * steps
-    fwd = 8 * ((nu * nx + nu) + (nx + nu) + (nx + nu) + 2 * m) * steps
-    return bwd, fwd
+    bwd = 8 * ((nx + nu) + (nu * nx + nu) + (m if fused else 2 * m)) * steps
+    if fused:
+        bwd += 8 * 2 * (nx + nu) * steps
+    fwd = 8 * ((nu * nx + nu) + (nx + nu) + (nx + nu)) * steps
+    return dict(backward=bwd, forward=fwd, apply=None, rollout=None)
 
 
-def cpu_baseline(cfg, inp, nb_iter, budget_s=12.0):
-    """The CPU oracle (oracle/ilqr_oracle.c, plain C restatement of the reference algorithm, -O3, one thread) timed on
-    a bounded sample of the SAME workload on this host.  Reported beside the GPU number, never inside it."""
-    from tests.helpers import oracle_solve_instance, panda_segs
+# ----------------------------------------------------------------------------- CPU baseline (the oracle, timed beside the GPU number)
+
+def cpu_baseline(cfg, inp, nb_iter, psi=None, budget_s=12.0):
+    """The CPU oracle (oracle/ilqr_oracle.c, plain C restatement of the reference algorithm, -O3, one thread) timed on a bounded sample
+    of the SAME workload on this host; then the same on all host cores.  Reported beside the GPU number, never inside it."""
+    from tests.helpers import oracle_solve_instance, oracle_system_of_instance, orc, panda_segs
 
     segs = panda_segs()
-    oracle_solve_instance(cfg, inp, 0, 1, False, segs)  # warm up (loads the .so)
+
+    def solve_one(i, s=None):
+        if cfg["solver"] == "batch_cp":
+            s = s or oracle_system_of_instance(cfg, inp, i, segs)
+            r = orc.solve_batch_cp(s, psi, inp["U0"][i].reshape(-1), nb_iter, False)
+            return dict(cost=float(r["trace_cost"][-1]), iters=r["iters"])
+        return oracle_solve_instance(cfg, inp, i, nb_iter, False, segs)
+
+    solve_one(0)  # warm up (loads the .so)
     n, t0 = 0, time.perf_counter()
     B = inp["q0"].shape[0]
-    costs = []
+    res = []
     while n < B:
-        r = oracle_solve_instance(cfg, inp, n, nb_iter, False, segs)
-        costs.append(r["cost"])
+        res.append(solve_one(n))
         n += 1
         if time.perf_counter() - t0 > budget_s and n >= 8:
             break
     dt = time.perf_counter() - t0
     out = dict(value=n * nb_iter / dt, unit="problem-iterations/s", cores=1, kind="port",
                sample=f"first {n} instances of the same seeded batch x {nb_iter} iterations, {dt:.1f} s, single thread")
-    # the same restatement on all host cores (instances are independent; ctypes releases the GIL around the C call): a second,
-    # shorter sample, reported beside the single-thread figure
-    try:
+    try:  # the same restatement on all host cores (instances are independent; ctypes releases the GIL around the C call)
         from concurrent.futures import ThreadPoolExecutor
 
         nthr = min(16, max(1, len(os.sched_getaffinity(0))))  # a one-GPU box is given 16 cores' worth of CPU
         if nthr > 1:
-            from tests.helpers import oracle_system_of_instance, orc
-
             pool = min(B, 4 * nthr)
             systems = [oracle_system_of_instance(cfg, inp, i, segs) for i in range(pool)]  # built outside the timed region (Python, holds the GIL)
-
-            def solve(k):
-                i, s = k % pool, systems[k % pool]
-                u0 = inp["U0"][i].reshape(-1)
-                if cfg["solver"] == "al":
-                    al = cfg["al"]
-                    orc.solve_al(s, inp["A"], inp["b"], inp["lambda0"][i], u0, nb_iter, al["lag"], al["penalty"], al["scaling"], True, False)
-                else:
-                    orc.solve_recursive(s, u0, nb_iter, True, False)
-
             deadline = time.perf_counter() + 5.0
             done = [0] * nthr
 
             def worker(w):
                 k = w
                 while time.perf_counter() < deadline:
-                    solve(k)
+                    i = k % pool
+                    if cfg["solver"] == "batch_cp":
+                        orc.solve_batch_cp(systems[i], psi, inp["U0"][i].reshape(-1), nb_iter, False)
+                    elif cfg["solver"] == "al":
+                        al = cfg["al"]
+                        orc.solve_al(systems[i], inp["A"], inp["b"], inp["lambda0"][i], inp["U0"][i].reshape(-1), nb_iter, al["lag"], al["penalty"],
+                                     al["scaling"], True, False)
+                    else:
+                        orc.solve_recursive(systems[i], inp["U0"][i].reshape(-1), nb_iter, True, False)
                     k += nthr
                     done[w] += 1
 
@@ -117,8 +177,49 @@ def cpu_baseline(cfg, inp, nb_iter, budget_s=12.0):
             out["all_cores"] = dict(value=sum(done) * nb_iter / dt2, cores=nthr, sample=f"{sum(done)} instances, {dt2:.1f} s, {nthr} threads")
     except Exception as e:  # the baseline is informative only
         out["all_cores"] = dict(error=str(e))
-    return out, costs
+    out["reference_published_not_measured_here"] = dict(  # the reference's own published timing, for orientation only
+        value=745, unit="iterations/s", what="ILQRRecursive, PosOrn 1st order, T=100, one instance, one thread, unknown CPU",
+        source="pylqr_planner/Tutorials/POS_ORN_SYS.ipynb:342-348 (time= fields of the stored output; BASELINE.md)")
+    return out, res
 
+
+def parity_report(ctx, cfg, desc, inp, B, nb_iter, oracle_res):
+    """Per-instance parity proof on the instances the CPU-baseline leg solved with the oracle, for both kernel sets (tests/parity_proof.py):
+    every sampled instance is within 1e-4 of the oracle's end-to-end run, or each of its GPU iterations is reproduced by one oracle
+    iteration from the GPU's own state (same step size, cost to 1e-9; rounding-level ties and ill-conditioned steps are named)."""
+    import numpy as np
+
+    from ilqr_planner_amd import workloads
+    from tests import parity_proof as pp
+
+    out = {}
+    n = len(oracle_res)
+    prev = os.environ.get("ILQR_HIP_PATH")
+    try:
+        for path in ("v2", "v1"):
+            os.environ["ILQR_HIP_PATH"] = path
+            p = workloads.load_batch(ctx, desc, inp, B)
+            workloads.run_solver(p, cfg, nb_iter=nb_iter, early_stop=False)
+            summ, rel, failures = pp.check_batch(p, cfg, inp, nb_iter, False, workloads.run_solver, lambda i: oracle_res[i], always=(0, 1),
+                                                 indices=range(n))
+            p.close()
+            r = rel[:n][np.isfinite(rel[:n])]
+            out[path] = {"n": n, "frac_within_1e-4": summ["frac_within_1e4"], "frac_proven_tie": summ["frac_proven_tie"],
+                         "frac_proven_stepwise": summ["frac_proven_stepwise"], "frac_unexplained": summ["frac_unexplained"],
+                         "final_cost_rel_err": {"median": float(np.median(r)), "p90": float(np.quantile(r, 0.9)), "max": float(r.max())},
+                         "unexplained_instances": [f["i"] for f in failures]}
+    finally:
+        if prev is None:
+            os.environ.pop("ILQR_HIP_PATH", None)
+        else:
+            os.environ["ILQR_HIP_PATH"] = prev
+    out["note"] = ("within = final cost within 1e-4 relative of the oracle's own end-to-end solve; proven = outside it, but every GPU iteration is "
+                   "one oracle iteration from the GPU's own state (stepwise), up to rounding-level ties of the reference's decisions (tie); "
+                   "the reference's map is expanding far from convergence, so end-to-end distances grow from 1e-13 per iteration")
+    return out
+
+
+# ----------------------------------------------------------------------------- main
 
 def main():
     ap = argparse.ArgumentParser()
@@ -126,15 +227,16 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="C3", help="workload (ilqr_planner_amd.workloads.config); C3 = the metric's configuration")
-    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--batch", type=int, default=None, help="instances per GPU (default: the configuration's per-GPU batch)")
     ap.add_argument("--iters", type=int, default=None)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU-baseline sample and the parity report (profiler runs)")
+    ap.add_argument("--gather-trajectories", action="store_true", help="N>1: also gather X / U to rank 0 every step")
     args = ap.parse_args()
 
     import numpy as np
     import torch
 
-    from ilqr_planner_amd import capi, workloads
+    from ilqr_planner_amd import capi, sharding, workloads
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -154,7 +256,10 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     cfg = workloads.config(args.config)
-    B = int(args.batch or cfg["B"])
+    B = int(args.batch or cfg["B"])        # per-GPU shard (weak scaling): C4 = 4096 per GPU, 32768 over 8
+    total = world * B
+    lo, hi = sharding.shard_range(total, rank, world)
+    assert hi - lo == B
     nb_iter = int(args.iters or cfg["nb_iter"])
     ctx = capi.Context(local_rank)
     stream = torch.cuda.Stream()  # a real (non-null) stream shared by the library's launches and torch's collectives
@@ -162,81 +267,74 @@ def main():
     ctx.set_stream(stream.cuda_stream)
     desc, inp = workloads.make_batch(ctx, cfg, B=B, seed=cfg["seed"] + 1000 * rank)
     p = workloads.load_batch(ctx, desc, inp, B)  # inputs resident in HBM from here on
-    psi = None
-    if cfg["solver"] == "batch_cp":
-        from tests.helpers import psi_of
-
-        psi = psi_of(cfg["psi"], cfg["T"], p.dims.n_u)
+    nx, nu = p.dims.n_x, p.dims.n_u
+    psi = workloads.psi_of(cfg["psi"], cfg["T"], nu) if cfg["solver"] == "batch_cp" else None
     cost_dev = torch.empty(B, dtype=torch.float64, device="cuda")
-    gathered = torch.empty(world * B, dtype=torch.float64, device="cuda") if world > 1 else None
+    X_dev = torch.empty((B, cfg["T"], nx), dtype=torch.float64, device="cuda") if args.gather_trajectories and world > 1 else None
+    U_dev = torch.empty((B, cfg["T"] - 1, nu), dtype=torch.float64, device="cuda") if X_dev is not None else None
 
     def step():
         if cfg["solver"] == "al":
             p.reset_multipliers()
         workloads.run_solver(p, cfg, nb_iter=nb_iter, early_stop=False, psi=psi)
         p.get_cost_dev(cost_dev.data_ptr())
+        if X_dev is not None:
+            p.get_X_dev(X_dev.data_ptr())
+            p.get_U_dev(U_dev.data_ptr())
         if world > 1:
-            dist.all_gather_into_tensor(gathered, cost_dev)  # the one collective: converged costs over RCCL/xGMI
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+            gather_step(cost_dev, total, X_dev, U_dev)  # the one collective: converged costs (+ trajectories) over RCCL/xGMI
 
     for _ in range(args.warmup):
         step()
-    ctx.profile_reset()
-    if not os.environ.get("ILQR_BENCH_NOPROF"):
-        ctx.profile(True)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
     ctx.profile(False)
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = max_over_ranks(timed_region(step, args.steps, torch.cuda.synchronize, dist), dist, "cuda")
 
+    # second pass, per-launch HIP events on: kernel durations for the roofline (not part of the headline)
+    ctx.profile_reset()
+    ctx.profile(True)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    ctx.profile(False)
     prof = {n: ctx.profile_get(w) for n, w in (("rollout", capi.PROF_ROLLOUT), ("backward", capi.PROF_BACKWARD), ("forward", capi.PROF_FORWARD),
-                                               ("apply", capi.PROF_APPLY))}
+                                               ("apply", capi.PROF_APPLY), ("other", capi.PROF_OTHER))}
     cost = cost_dev.cpu().numpy()
     status = p.status()
-    at = p.trace(nb_iter)[1] if cfg["solver"] != "batch_cp" else None
+    riccati = cfg["solver"] != "batch_cp"
+    at = p.trace(nb_iter)[1] if riccati else None
 
     if rank == 0:
-        nx, nu, m = p.dims.n_x, p.dims.n_u, p.m
-        bwd_bytes, fwd_bytes = algorithmic_bytes(nx, nu, m, cfg["T"], B)
-        # mean number of step sizes the reference's do/while would have tried, and the share of instance-iterations whose
-        # winner was not alpha = 1 (those are re-rolled by the second forward pass)
-        trials = float(np.mean(1 + np.round(-np.log2(at)))) if at is not None else 1.0
-        frac_apply = float(np.mean(at < 1.0)) if at is not None else 0.0
+        m = p.m
         v1 = os.environ.get("ILQR_HIP_PATH") == "v1"
+        fused = (not v1) and cfg["kind"] in (0, 2) and cfg["nb_deriv"] == 1 and riccati
+        alg = algorithmic_bytes(cfg, nx, nu, m, B, fused)
+        trials = float(np.mean(1 + np.round(-np.log2(at)))) if at is not None else None
         kern = {}
-        # algorithmic bytes per launch.  backward: read x,u (+lambda,I) ; write K,d.  forward: v1 = one full read+write per
-        # sequential trial; v2 = ONE pass over K,d,x,u (+ write of x(1),u(1)) whatever the number of trials.  "apply" is the
-        # elementwise blend of the winner (read xbar,ubar,x(1),u(1); write x,u) for the instance-iterations with alpha != 1.
-        blend_bytes = 8 * 3 * (nx + nu) * (cfg["T"] - 1) * B * frac_apply
-        for name, byts in (("backward", bwd_bytes), ("forward", fwd_bytes * (trials if v1 else 1.0)), ("apply", blend_bytes)):
+        for name in ("rollout", "backward", "forward", "apply", "other"):
             ms, n = prof[name]
             if n:
                 avg = ms / n
-                kern[name] = dict(avg_ms=avg, launches=n, total_ms=ms, alg_bytes=byts, gbs=byts / (avg * 1e-3) / 1e9)
-        dom = max(kern, key=lambda k: kern[k]["total_ms"]) if kern else None
+                byts = alg.get(name)
+                if byts is not None and name == "forward" and v1:
+                    byts = byts * trials  # the generic kernels re-roll the horizon once per trial
+                kern[name] = dict(avg_ms=avg, launches=n, total_ms=ms, alg_bytes=byts, gbs=(byts / (avg * 1e-3) / 1e9) if byts else None)
+        rated = {k: v for k, v in kern.items() if v["alg_bytes"]}
+        dom = max(rated, key=lambda k: rated[k]["total_ms"]) if rated else None
         roof = None
         if dom:
             k = kern[dom]
-            traffic, traffic_src = pmc_traffic(dom) if args.config == "C3" and not v1 else (None, None)
+            traffic, traffic_src = pmc_traffic(args.config, dom) if not v1 else (None, None)
             roof = dict(bound="hbm", kernel=dom, achieved=round(k["gbs"], 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(k["gbs"] / HBM_PEAK_GBS, 5),
                         traffic=traffic, traffic_source=traffic_src, avg_launch_ms=round(k["avg_ms"], 4), alg_bytes_per_launch=int(k["alg_bytes"]),
-                        other={n: dict(avg_launch_ms=round(v["avg_ms"], 4), achieved=round(v["gbs"], 2)) for n, v in kern.items() if n != dom},
-                        mean_line_search_trials=round(trials, 3))
+                        launches_per_step={n_: v["launches"] // 2 for n_, v in kern.items()},
+                        other={n_: dict(avg_launch_ms=round(v["avg_ms"], 4), achieved=round(v["gbs"], 2) if v["gbs"] else None) for n_, v in kern.items() if n_ != dom},
+                        timing="HIP events on the library's stream, separate pass after the timed region")
+            if trials is not None:
+                roof["mean_line_search_trials"] = round(trials, 3)
+        kinds = ("PosOrn", "PosOrnTime", "JointSpace", "JointSpaceTime")
         out = {
-            "metric": "iLQR iterations/sec (7-DoF, T=200, batch 4096) + final-cost rel-err vs Eigen ref",
-            "value": world * B * nb_iter * args.steps / elapsed,
+            "metric": METRIC,
+            "value": total * nb_iter * args.steps / elapsed,
             "unit": "problem-iterations/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -247,26 +345,27 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{args.config}: {('PosOrn', 'PosOrnTime', 'JointSpace', 'JointSpaceTime')[cfg['kind']]} nb_deriv={cfg['nb_deriv']} "
+            "config": {"workload": f"{args.config}: {kinds[cfg['kind']]} nb_deriv={cfg['nb_deriv']} "
                                    f"{'7-DoF Panda chain' if cfg['kind'] < 2 else str(cfg.get('dof', 7)) + ' joints'}, "
-                                   f"T={cfg['T']}, batch {B}/GPU, solver={cfg['solver']}, {nb_iter} iterations/solve, line search on, early stop off",
-                       "global_batch": world * B, "horizon": cfg["T"], "iterations_per_step": nb_iter, "parallelism": f"instances sharded x{world}"},
+                                   f"T={cfg['T']}, batch {B}/GPU x {world} GPU = {total}, solver={cfg['solver']}, {nb_iter} iterations/solve, "
+                                   f"{'line search on, ' if riccati else ''}early stop off",
+                       "global_batch": total, "horizon": cfg["T"], "iterations_per_step": nb_iter, "parallelism": f"instances sharded x{world}",
+                       "exchange": "all-gather of costs" + (" + gather of X, U to rank 0" if X_dev is not None else "") if world > 1 else "none"},
             "batch_sweeps_per_s": nb_iter * args.steps / elapsed,
             "nonfinite_frac": float(np.mean((status & 1) != 0)),
             "roofline": roof,
         }
-        if not args.no_cpu_baseline and world == 1 and cfg["solver"] != "batch_cp":  # the CPU baseline belongs to the N = 1 line only
-            cb, ccost = cpu_baseline(cfg, inp, nb_iter)
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline and the parity report belong to the N = 1 line only
+            cb, ores = cpu_baseline(cfg, inp, nb_iter, psi)
             out["cpu_baseline"] = cb
-            # the reference's own published timing, for orientation only: not measured here, other hardware, other horizon
-            cb["reference_published_not_measured_here"] = dict(
-                value=745, unit="iterations/s", what="ILQRRecursive, PosOrn 1st order, T=100, one instance, one thread, unknown CPU",
-                source="pylqr_planner/Tutorials/POS_ORN_SYS.ipynb:342-348 (time= fields of the stored output; BASELINE.md)")
-            ref = np.array(ccost)
-            rel = np.abs(cost[: len(ref)] - ref) / np.maximum(np.abs(ref), 1e-12)
-            out["final_cost_rel_err_vs_oracle"] = {"median": float(np.median(rel)), "p90": float(np.quantile(rel, 0.9)), "max": float(rel.max()),
-                                                   "frac_within_1e-4": float(np.mean(rel <= 1e-4)), "n": int(len(ref)),
-                                                   "note": "AL-iLQR is a discontinuous map: instances outside 1e-4 are those where the oracle itself moves by >1e-7 under a 1e-15 perturbation of q0 (DESIGN.md, Parity)"}
+            if riccati:
+                out["parity"] = parity_report(ctx, cfg, desc, inp, B, nb_iter, ores)
+            else:  # batch solvers report the cost before each step: compare the last trace entry
+                ct = p.trace(nb_iter)[0]
+                ref = np.array([r["cost"] for r in ores])
+                rel = np.abs(ct[: len(ref), nb_iter - 1] - ref) / np.maximum(np.abs(ref), 1e-12)
+                out["parity"] = {"n": int(len(ref)), "frac_within_1e-4": float(np.mean(rel <= 1e-4)),
+                                 "final_cost_rel_err": {"median": float(np.median(rel)), "p90": float(np.quantile(rel, 0.9)), "max": float(rel.max())}}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

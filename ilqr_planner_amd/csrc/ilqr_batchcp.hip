@@ -546,7 +546,7 @@ void batchcp_free(BatchCPState& st) {
 }
 
 template <class S, int KWP>
-static int run_cp(BatchCPState& st, const DevDesc& h, Bufs& bufs, int nb_iter, int early_stop, hipStream_t stream, std::string& err) {
+static int run_cp(BatchCPState& st, const DevDesc& h, Bufs& bufs, int nb_iter, int early_stop, hipStream_t stream, std::string& err, const ProfHook& ph) {
     constexpr int NX = S::NX;
     const int B = h.B;
     const dim3 grid((B + LPB - 1) / LPB), block(LPB);
@@ -560,17 +560,21 @@ static int run_cp(BatchCPState& st, const DevDesc& h, Bufs& bufs, int nb_iter, i
     c.Kw = st.Kw; c.early_stop = early_stop; c.n_alpha = 11; c.it = 0;
     c.wref = nullptr;
     const bool wave_solve = !(std::getenv("ILQR_CP_SOLVE") && !std::strcmp(std::getenv("ILQR_CP_SOLVE"), "lane"));  // cross-check: lane per instance
+    ph(ILQR_PROF_ROLLOUT);
     hipLaunchKernelGGL((k_cp_init<S>), dim3((B + 255) / 256), dim3(256), 0, stream, bufs);
     for (int it = 0; it < nb_iter; it++) {
         c.it = it;
+        ph(ILQR_PROF_BACKWARD);  // linearisation + normal equations + du = PSI dw
         hipLaunchKernelGGL((k_cp_linearize<S, KWP>), dim3((B + 64 / KWP - 1) / (64 / KWP)), dim3(64), 0, stream, bufs, c);
         if (wave_solve) hipLaunchKernelGGL((k_cp_solve_w<S, KWP>), dim3(B), dim3(64), 0, stream, bufs, c);
         else hipLaunchKernelGGL((k_cp_solve<S, KWP>), grid, block, lds_h, stream, bufs, c);
         hipLaunchKernelGGL((k_cp_du<S, KWP>), dim3((B + 63) / 64, h.T - 1), dim3(64), 0, stream, bufs, c);
         BTArgs bt;
         bt.it = it; bt.early_stop = early_stop;
+        ph(ILQR_PROF_FORWARD);   // backtracking over all step sizes (rollouts)
         hipLaunchKernelGGL((k_bt_linesearch<S>), dim3((B + 3) / 4), dim3(64), 0, stream, bufs, bt);
     }
+    ph(ILQR_PROF_APPLY);
     hipLaunchKernelGGL((k_cp_final<S>), grid, block, 0, stream, bufs);
     if (hipGetLastError() != hipSuccess) { err = "ilqr_solve_batch_cp: kernel launch failed"; return 1; }
     return 0;
@@ -579,7 +583,7 @@ static int run_cp(BatchCPState& st, const DevDesc& h, Bufs& bufs, int nb_iter, i
 // PosOrn systems: iterate in coefficient space (see the kernels above).  psip = PSI padded to KWP columns (host copy).
 template <class S, int KWP>
 static int run_cpl(BatchCPState& st, const DevDesc& h, Bufs& bufs, const std::vector<double>& psip, int nb_iter, int early_stop, hipStream_t stream,
-                   std::string& err) {
+                   std::string& err, const ProfHook& ph) {
     constexpr int NX = S::NX, NU = S::NU, ND = S::ND;
     const int B = h.B, T = h.T, nkp = h.n_kp;
     const double dt = h.dt, hdt2 = dt * dt / 2;
@@ -631,15 +635,19 @@ static int run_cpl(BatchCPState& st, const DevDesc& h, Bufs& bufs, const std::ve
     c.Kw = st.Kw; c.early_stop = early_stop; c.n_alpha = 11; c.it = 0;
     c.wref = st.wref;
     const bool wave_solve = !(std::getenv("ILQR_CP_SOLVE") && !std::strcmp(std::getenv("ILQR_CP_SOLVE"), "lane"));  // cross-check: lane per instance
+    ph(ILQR_PROF_ROLLOUT);   // rollout of u0, its keypoint states and the quadratic forms of the control cost (walks the horizon)
     hipLaunchKernelGGL((k_cpl_init<S, KWP>), dim3((B + 64 / KWP - 1) / (64 / KWP)), dim3(64), 0, stream, bufs, c);
     if (nkp > 0) hipLaunchKernelGGL(k_cpl_bcast, dim3((B + 255) / 256, nkp * NX * KWP), dim3(256), 0, stream, st.wref, st.Wkp, nkp * NX * KWP, B, h.Bp);
     for (int it = 0; it < nb_iter; it++) {
         c.it = it;
+        ph(ILQR_PROF_BACKWARD);  // keypoint linearisation + the Kw x Kw normal equations
         hipLaunchKernelGGL((k_cpl_linearize<S, KWP>), dim3((B + LPB - 1) / LPB, nkp > 0 ? nkp : 1), block, 0, stream, bufs, c);
         if (wave_solve) hipLaunchKernelGGL((k_cp_solve_w<S, KWP>), dim3(B), dim3(64), 0, stream, bufs, c);
         else hipLaunchKernelGGL((k_cp_solve<S, KWP>), grid, block, lds_h, stream, bufs, c);
+        ph(ILQR_PROF_FORWARD);   // all step sizes of the backtracking, in coefficient space
         hipLaunchKernelGGL((k_cpl_linesearch<S, KWP>), dim3((B + 3) / 4), dim3(64), 0, stream, bufs, c);
     }
+    ph(ILQR_PROF_APPLY);     // u = u0 + PSI w and the final rollout (walks the horizon)
     hipLaunchKernelGGL((k_cpl_controls<S, KWP>), dim3((B + 63) / 64, T - 1), dim3(64), 0, stream, bufs, c);
     hipLaunchKernelGGL((k_cp_final<S>), grid, block, 0, stream, bufs);
     if (hipGetLastError() != hipSuccess) { err = "ilqr_solve_batch_cp: kernel launch failed"; return 1; }
@@ -647,7 +655,7 @@ static int run_cpl(BatchCPState& st, const DevDesc& h, Bufs& bufs, const std::ve
 }
 
 int batchcp_solve(BatchCPState& st, const DevDesc& h, Bufs& bufs, int nx, int nu, int nf, int nq, const double* psi_host, int Kw,
-                  int nb_iter, int early_stop, hipStream_t stream, std::string& err) {
+                  int nb_iter, int early_stop, hipStream_t stream, std::string& err, const ProfHook& ph) {
     (void)nf; (void)nq;
     if (!psi_host || Kw <= 0) { err = "ilqr_solve_batch_cp: null PSI / Kw <= 0"; return 1; }
     const bool time_sys = h.kind == 1 || h.kind == 3;
@@ -687,19 +695,19 @@ int batchcp_solve(BatchCPState& st, const DevDesc& h, Bufs& bufs, int nx, int nu
     }
     static const bool general = std::getenv("ILQR_CP") && !std::strcmp(std::getenv("ILQR_CP"), "general");  // cross-check path
     if (KWP == 32) {  // wider bases on the time systems: the same kernels with 32 lanes per instance
-        if (h.kind == 3) return run_cp<Sys<3, 1>, 32>(st, h, bufs, nb_iter, early_stop, stream, err);
-        if (h.nd == 1) return run_cp<Sys<1, 1>, 32>(st, h, bufs, nb_iter, early_stop, stream, err);
-        return run_cp<Sys<1, 2>, 32>(st, h, bufs, nb_iter, early_stop, stream, err);
+        if (h.kind == 3) return run_cp<Sys<3, 1>, 32>(st, h, bufs, nb_iter, early_stop, stream, err, ph);
+        if (h.nd == 1) return run_cp<Sys<1, 1>, 32>(st, h, bufs, nb_iter, early_stop, stream, err, ph);
+        return run_cp<Sys<1, 2>, 32>(st, h, bufs, nb_iter, early_stop, stream, err, ph);
     }
-    if (h.kind == 3) return run_cp<Sys<3, 1>, 16>(st, h, bufs, nb_iter, early_stop, stream, err);
-    if (h.kind == 2 && !general) return run_cpl<Sys<2, 1>, 16>(st, h, bufs, psip, nb_iter, early_stop, stream, err);
-    if (h.kind == 2) return run_cp<Sys<2, 1>, 16>(st, h, bufs, nb_iter, early_stop, stream, err);
-    if (h.kind == 0 && h.nd == 1 && !general) return run_cpl<Sys<0, 1>, 16>(st, h, bufs, psip, nb_iter, early_stop, stream, err);
-    if (h.kind == 0 && h.nd == 2 && !general) return run_cpl<Sys<0, 2>, 16>(st, h, bufs, psip, nb_iter, early_stop, stream, err);
-    if (h.kind == 0 && h.nd == 1) return run_cp<Sys<0, 1>, 16>(st, h, bufs, nb_iter, early_stop, stream, err);
-    if (h.kind == 0 && h.nd == 2) return run_cp<Sys<0, 2>, 16>(st, h, bufs, nb_iter, early_stop, stream, err);
-    if (h.kind == 1 && h.nd == 1) return run_cp<Sys<1, 1>, 16>(st, h, bufs, nb_iter, early_stop, stream, err);
-    return run_cp<Sys<1, 2>, 16>(st, h, bufs, nb_iter, early_stop, stream, err);
+    if (h.kind == 3) return run_cp<Sys<3, 1>, 16>(st, h, bufs, nb_iter, early_stop, stream, err, ph);
+    if (h.kind == 2 && !general) return run_cpl<Sys<2, 1>, 16>(st, h, bufs, psip, nb_iter, early_stop, stream, err, ph);
+    if (h.kind == 2) return run_cp<Sys<2, 1>, 16>(st, h, bufs, nb_iter, early_stop, stream, err, ph);
+    if (h.kind == 0 && h.nd == 1 && !general) return run_cpl<Sys<0, 1>, 16>(st, h, bufs, psip, nb_iter, early_stop, stream, err, ph);
+    if (h.kind == 0 && h.nd == 2 && !general) return run_cpl<Sys<0, 2>, 16>(st, h, bufs, psip, nb_iter, early_stop, stream, err, ph);
+    if (h.kind == 0 && h.nd == 1) return run_cp<Sys<0, 1>, 16>(st, h, bufs, nb_iter, early_stop, stream, err, ph);
+    if (h.kind == 0 && h.nd == 2) return run_cp<Sys<0, 2>, 16>(st, h, bufs, nb_iter, early_stop, stream, err, ph);
+    if (h.kind == 1 && h.nd == 1) return run_cp<Sys<1, 1>, 16>(st, h, bufs, nb_iter, early_stop, stream, err, ph);
+    return run_cp<Sys<1, 2>, 16>(st, h, bufs, nb_iter, early_stop, stream, err, ph);
 }
 
 }  // namespace ilqr

@@ -5,9 +5,18 @@
 #include <string>
 #include <vector>
 
+#include "../../include/ilqr_hip.h"  // ILQR_PROF_* categories
 #include "ilqr_kernels.hpp"
 
 namespace ilqr {
+
+// Per-launch timing hook handed in by the C ABI layer (HIP-event marks of ilqr_profile_*): hook(ILQR_PROF_x) in front of a launch charges
+// the time until the next mark to category x.  Empty hook = profiling off.
+struct ProfHook {
+    void (*mark)(void*, int) = nullptr;
+    void* ctx = nullptr;
+    void operator()(int which) const { if (mark) mark(ctx, which); }
+};
 
 // Device buffers of the control-primitive solver; sized for one (problem, Kw) pair and reused across solves.
 struct BatchCPState {
@@ -54,11 +63,11 @@ struct BatchWideState {
            *Ckp = nullptr, *rkp = nullptr, *u0hat = nullptr, *g0 = nullptr, *y0 = nullptr, *psi = nullptr, *h0inv = nullptr;
 };
 int batchwide_solve(BatchWideState& st, const DevDesc& h, Bufs& bufs, int nx, int nu, const double* psi_host, int Kw, int nb_iter, int early_stop,
-                    bool u0_zero, hipStream_t stream, std::string& err);
+                    bool u0_zero, hipStream_t stream, std::string& err, const ProfHook& ph = ProfHook());
 void batchwide_free(BatchWideState& st);
 
 int batchcp_solve(BatchCPState& st, const DevDesc& h, Bufs& bufs, int nx, int nu, int nf, int nq, const double* psi_host, int Kw,
-                  int nb_iter, int early_stop, hipStream_t stream, std::string& err);
+                  int nb_iter, int early_stop, hipStream_t stream, std::string& err, const ProfHook& ph = ProfHook());
 void batchcp_free(BatchCPState& st);
 
 }  // namespace ilqr

@@ -855,8 +855,9 @@ static int run_wt_m(BatchWideState& st, const DevDesc& h, Bufs& bufs, int nb_ite
 }
 
 int batchwide_solve(BatchWideState& st, const DevDesc& h, Bufs& bufs, int nx, int nu, const double* psi_host, int Kw, int nb_iter, int early_stop,
-                    bool u0_zero, hipStream_t stream, std::string& err) {
+                    bool u0_zero, hipStream_t stream, std::string& err, const ProfHook& ph) {
     (void)nx;
+    ph(ILQR_PROF_BACKWARD);  // the whole wide-basis solve is charged to one category
     const int N = (h.T - 1) * nu;
     if (nb_iter < 0) { err = "nb_iter < 0"; return 1; }
     if (h.n_kp <= 0) { err = "wide-basis batch solve: the system has no keypoint"; return 1; }

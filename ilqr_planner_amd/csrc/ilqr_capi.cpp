@@ -173,10 +173,18 @@ static void prof_mark(ilqr_ctx* c, int which) {  // which < 0: end mark (closes 
     hipEvent_t e = ev_get(c);
     (void)hipEventRecord(e, c->stream);
     c->pending.push_back({e, nullptr, which});
+    if (which < 0 && c->pending.size() > 4096) prof_collect(c);  // synchronises; only with profiling on and only every few hundred solves
 }
 struct ProfScope {  // marks the launch that follows; the interval is closed by the next mark
     ProfScope(ilqr_ctx* c, int w) { prof_mark(c, w); }
 };
+
+static void prof_hook_fn(void* c, int which) { prof_mark((ilqr_ctx*)c, which); }
+static ilqr::ProfHook prof_hook(ilqr_ctx* c) {
+    ilqr::ProfHook h;
+    if (c->profile) { h.mark = prof_hook_fn; h.ctx = c; }
+    return h;
+}
 
 extern "C" int ilqr_profile_enable(ilqr_ctx* c, int on) {
     if (!c) return 1;
@@ -430,6 +438,18 @@ extern "C" int ilqr_problem_set_constraints(ilqr_problem* p, int m, int per_step
     const int ns = p->dims.n_x + p->dims.n_u, T = p->T;
     const size_t nk = per_step ? (size_t)(T - 1) : 1;
     if (p->bufs.m != m || p->bufs.per_step != per_step || !p->conA) {
+        if (p->conA) {  // another shape: release the previous constraint buffers (nothing in flight may still read them)
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            void* old[5] = {p->conA, p->conb, p->bufs.lambda, p->bufs.Is, p->lambda0};
+            for (void* q : old) {
+                for (auto it = p->allocs.begin(); it != p->allocs.end(); ++it)
+                    if (*it == q) { p->allocs.erase(it); break; }
+                (void)hipFree(q);
+            }
+            p->conA = p->conb = p->lambda0 = nullptr;
+            p->bufs.lambda = p->bufs.Is = nullptr;
+            p->bufs.m = 0;
+        }
         if (dalloc(p, &p->conA, nk * m * ns) || dalloc(p, &p->conb, nk * m)) return 1;
         double *lam, *Is;
         if (dalloc(p, &lam, (size_t)(T - 1) * m * p->Bp) || dalloc(p, &Is, (size_t)(T - 1) * m * p->Bp)) return 1;
@@ -595,11 +615,13 @@ extern "C" int ilqr_solve_batch_cp(ilqr_problem* p, const double* psi, int Kw, i
     p->last_nb_iter = nb_iter;
     const bool cp_time = p->desc.kind == ILQR_SYS_POS_ORN_TIME || p->desc.kind == ILQR_SYS_JOINT_TIME;
     if (psi && Kw > 16 && !(cp_time && Kw <= 32)) {  // wide basis: low-rank form of the normal equations (ilqr_batchwide.hip)
-        if (batchwide_solve(p->cpw, p->hdesc, p->bufs, p->dims.n_x, p->dims.n_u, psi, Kw, nb_iter, early_stop, p->u0_zero, c->stream, err)) return fail(c, err);
+        if (batchwide_solve(p->cpw, p->hdesc, p->bufs, p->dims.n_x, p->dims.n_u, psi, Kw, nb_iter, early_stop, p->u0_zero, c->stream, err, prof_hook(c))) return fail(c, err);
+        prof_mark(c, -1);
         return 0;
     }
-    if (batchcp_solve(p->cp, p->hdesc, p->bufs, p->dims.n_x, p->dims.n_u, p->dims.n_f, p->dims.n_Q, psi, Kw, nb_iter, early_stop, c->stream, err))
+    if (batchcp_solve(p->cp, p->hdesc, p->bufs, p->dims.n_x, p->dims.n_u, p->dims.n_f, p->dims.n_Q, psi, Kw, nb_iter, early_stop, c->stream, err, prof_hook(c)))
         return fail(c, err);
+    prof_mark(c, -1);
     return 0;
 }
 
@@ -611,7 +633,8 @@ extern "C" int ilqr_solve_batch(ilqr_problem* p, int nb_iter, int early_stop) {
     std::string err;
     if (ensure_trace(p, nb_iter)) return 1;
     p->last_nb_iter = nb_iter;
-    if (batchwide_solve(p->cpw, p->hdesc, p->bufs, p->dims.n_x, p->dims.n_u, nullptr, 0, nb_iter, early_stop, p->u0_zero, c->stream, err)) return fail(c, err);
+    if (batchwide_solve(p->cpw, p->hdesc, p->bufs, p->dims.n_x, p->dims.n_u, nullptr, 0, nb_iter, early_stop, p->u0_zero, c->stream, err, prof_hook(c))) return fail(c, err);
+    prof_mark(c, -1);
     return 0;
 }
 

@@ -179,6 +179,28 @@ def _make_joint_batch(cfg, B, seed, limits):
     return desc, inp
 
 
+def psi_of(spec: dict, T: int, n_u: int):
+    """Control-primitive basis of a batch_cp config, built with the product's own basis builders (PyLQR.utils.primitives, the mirror
+    of the reference's primitives.cpp) exactly as the tutorial cells combine them: kron(basis(T-1, K), I_nu)."""
+    import sys
+
+    pyl = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pylqr")
+    if pyl not in sys.path:
+        sys.path.insert(0, pyl)
+    from PyLQR.utils import primitives
+
+    build = dict(unitstep=primitives.build_psi_unitstep, sawtooth=primitives.build_psi_sawtooth, rbf=primitives.build_psi_RBF,
+                 bernstein=primitives.build_psi_bernstein)
+    K = spec["K"]
+    if spec["kind"] in build:
+        return np.kron(np.asarray(build[spec["kind"]](T - 1, K)), np.eye(n_u))
+    if spec["kind"] == "sawtooth+unitstep_dt":  # controls on a sawtooth basis, sqrt(dt) on unit steps (POS_ORN_TIME_SYS.ipynb)
+        a = np.diag([1.0] * (n_u - 1) + [0.0])
+        b = np.diag([0.0] * (n_u - 1) + [1.0])
+        return np.kron(np.asarray(primitives.build_psi_sawtooth(T - 1, K)), a) + np.kron(np.asarray(primitives.build_psi_unitstep(T - 1, K)), b)
+    raise KeyError(spec["kind"])
+
+
 def load_batch(ctx: capi.Context, desc, inp, B: int) -> capi.BatchProblem:
     p = capi.BatchProblem(ctx, desc, B)
     p.set_init_state(inp["q0"], inp["dq0"])

@@ -319,3 +319,40 @@ def test_warm_start_and_tracking(ctx):
     p.solve_recursive(4, True, False)
     assert np.all(p.cost() <= c0 + 1e-12)
     p.close()
+
+
+def test_tracking_and_warm_start_vs_oracle(ctx):
+    """SURVEY 8 row f-4 against the ORACLE (test_warm_start_and_tracking checks the definitions on the GPU's own outputs):
+    tracking  u = ubar_k + K_k (x - xbar_k) + alpha d_k  with the oracle's K, d, xbar, ubar of the same solve (POS_ORN_SYS.ipynb cell 7);
+    warm start = the oracle's solve from the shifted plan: U0'[k] = U[min(k + s, T-2)], start state x_s."""
+    from ilqr_planner_amd import workloads
+    from tests.helpers import oracle_system_of_instance
+
+    cfg = workloads.config("C2")
+    B, n1, n2, shift, k = 12, 6, 4, 5, 23
+    desc, inp = workloads.make_batch(ctx, cfg, B=B, seed=31)
+    p = workloads.load_batch(ctx, desc, inp, B)
+    p.solve_recursive(n1, True, False)
+    rng = np.random.default_rng(3)
+    first = [oracle_solve_instance(cfg, inp, i, n1, False) for i in range(B)]
+    # ---- tracking law with the oracle's gains
+    x_meas = np.stack([r["X"][k] for r in first]) + 1e-2 * rng.standard_normal((B, 7))
+    for ff in (False, True):
+        got = p.track(k, x_meas, ff)
+        for i, r in enumerate(first):
+            want = r["U"][k] + r["K"][k] @ (x_meas[i] - r["X"][k]) + (r["d"][k] if ff else 0.0)  # r["d"] is alpha-scaled (ILQRRecursive.cpp:162)
+            np.testing.assert_allclose(got[i], want, rtol=1e-6, atol=1e-8)
+    # ---- receding horizon: shift the plan by `shift` steps and re-plan; the oracle does the same from ITS first solve
+    p.warm_start(shift)
+    p.solve_recursive(n2, True, False)
+    cost2 = p.cost()
+    T = cfg["T"]
+    for i, r in enumerate(first):
+        U0 = np.vstack([r["U"][shift:], np.repeat(r["U"][-1:], shift, axis=0)])
+        inp2 = dict(inp, q0=inp["q0"].copy(), U0=inp["U0"].copy())
+        inp2["q0"][i] = r["X"][shift]
+        inp2["U0"][i] = U0
+        s = oracle_system_of_instance(cfg, inp2, i)
+        r2 = orc.solve_recursive(s, U0.reshape(-1), n2, True, False)
+        assert abs(cost2[i] - r2["cost"]) <= 1e-4 * max(abs(r2["cost"]), 1e-9), (i, cost2[i], r2["cost"])  # two chained solves: the north star's tolerance
+    p.close()

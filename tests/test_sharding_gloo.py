@@ -56,6 +56,74 @@ def _worker(rank, world, port, total, ret):
     dist.destroy_process_group()
 
 
+def _bench_worker(rank, world, port, total, ret):
+    """bench.py's own multi-rank plumbing (fence, timed_region, gather_step, max_over_ranks) with a stubbed solve: the stub lives here,
+    in the test -- the product has no CPU path."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import time
+
+    import bench
+    from ilqr_planner_amd.sharding import shard_range
+
+    lo, hi = shard_range(total, rank, world)
+    T, nx, nu = 5, 3, 2
+    calls = {"n": 0}
+    out = {}
+
+    def step():  # stand-in for "solve the shard, read the costs back": instance i costs i + 0.5, X[i] = i everywhere; rank 1 is slower
+        calls["n"] += 1
+        time.sleep(0.02 * (1 + rank))
+        cost = torch.arange(lo, hi, dtype=torch.float64) + 0.5
+        X = torch.arange(lo, hi, dtype=torch.float64)[:, None, None].expand(hi - lo, T, nx).contiguous()
+        U = -torch.arange(lo, hi, dtype=torch.float64)[:, None, None].expand(hi - lo, T - 1, nu).contiguous()
+        out.update(bench.gather_step(cost, total, X, U))
+
+    mine = bench.timed_region(step, 3, lambda: None, dist)
+    slowest = bench.max_over_ranks(mine, dist, "cpu")
+    assert calls["n"] == 3
+    assert slowest >= mine - 1e-9 and slowest >= 3 * 0.02 * world - 1e-3  # the MAX over ranks is rank (world-1)'s time
+    np.testing.assert_array_equal(out["cost"].numpy(), np.arange(total) + 0.5)  # every rank holds all costs, in instance order
+    if rank == 0:
+        assert out["X"].shape == (total, T, nx) and out["U"].shape == (total, T - 1, nu)
+        np.testing.assert_array_equal(out["X"][:, 0, 0].numpy(), np.arange(total))
+        np.testing.assert_array_equal(out["U"][:, -1, -1].numpy(), -np.arange(total, dtype=float))
+        ret.put((mine, slowest))
+    else:
+        assert out["X"] is None and out["U"] is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_multirank_plumbing_under_gloo():
+    """bench.py's N>1 code path on CPU: world-size-2 gloo, ragged shards (4 + 3), fence + gather of costs and trajectories + MAX of
+    the per-rank wall times -- the functions bench.py's main() calls, not copies of them."""
+    total, world = 7, 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, total, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    mine, slowest = ret.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert slowest >= mine
+
+
+def test_bench_helpers_single_process():
+    """Without a process group the helpers degrade to the single-GPU case."""
+    import bench
+
+    n = {"k": 0}
+    t = bench.timed_region(lambda: n.__setitem__("k", n["k"] + 1), 4, lambda: None, None)
+    assert n["k"] == 4 and t >= 0
+    assert bench.max_over_ranks(1.25, None) == 1.25
+
+
 def test_shard_range_partitions():
     from ilqr_planner_amd.sharding import shard_range
 
