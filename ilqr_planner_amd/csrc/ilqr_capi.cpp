@@ -33,6 +33,9 @@ struct ilqr_ctx {
     std::vector<Pending> pending;
     std::vector<hipEvent_t> pool;
     std::vector<ilqr_problem*> problems;  // live problems of this context (destroyed with it)
+    // split solves (solve_riccati): the two halves of a batch run on their own streams, joined to `stream` by events
+    hipStream_t half_stream[2] = {nullptr, nullptr};
+    hipEvent_t ev_begin = nullptr, ev_half_done[2] = {nullptr, nullptr}, ev_stagger = nullptr;
 };
 
 struct ilqr_problem {
@@ -42,6 +45,8 @@ struct ilqr_problem {
     int B = 0, Bp = 0, T = 0;
     DevDesc hdesc;
     DevDesc* ddesc = nullptr;
+    DevDesc* ddesc_half[2] = {nullptr, nullptr};  // the descriptor with B = the half's instance count (split solves)
+    int half_b0[2] = {0, 0}, half_B[2] = {0, 0};
     Bufs bufs;
     std::vector<void*> allocs;
     double *conA = nullptr, *conb = nullptr;  // device copies of the shared constraint rows
@@ -56,6 +61,11 @@ struct ilqr_problem {
     BatchCPState cp;
     BatchWideState cpw;
 };
+
+// Batches of at least this many instances may be solved as two halves on two streams (solve_riccati): every kernel of an iteration is a
+// chain of T dependent steps that leaves much of the machine idle at these batch sizes, so one half's sweep can run under the other
+// half's forward pass and decision.
+constexpr int SPLIT_MIN_BATCH = 2048;
 
 static int fail(ilqr_ctx* c, const std::string& m) {
     if (c) c->err = m;
@@ -122,6 +132,12 @@ extern "C" void ilqr_ctx_destroy(ilqr_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto& p : c->pending) (void)hipEventDestroy(p.a);
     for (auto e : c->pool) (void)hipEventDestroy(e);
+    for (int i = 0; i < 2; i++) {
+        if (c->half_stream[i]) (void)hipStreamDestroy(c->half_stream[i]);
+        if (c->ev_half_done[i]) (void)hipEventDestroy(c->ev_half_done[i]);
+    }
+    if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
+    if (c->ev_stagger) (void)hipEventDestroy(c->ev_stagger);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -352,8 +368,21 @@ extern "C" int ilqr_problem_create(ilqr_ctx* c, const ilqr_problem_desc* d, int 
     rc |= dalloc(p, &b.kpd, (size_t)(d->n_kp > 0 ? d->n_kp : 1) * (NX + NX * NX) * Bp);
     if (rc) { ilqr_problem_destroy(p); return 1; }
     b.U0 = U0; b.q0 = q0; b.dq0 = dq0; b.kp_tg = tg; b.desc = p->ddesc;
-    if (hipMemcpyAsync(p->ddesc, &p->hdesc, sizeof(DevDesc), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-        hipStreamSynchronize(c->stream) != hipSuccess) {
+    bool up_ok = hipMemcpyAsync(p->ddesc, &p->hdesc, sizeof(DevDesc), hipMemcpyHostToDevice, c->stream) == hipSuccess;
+    if (p->B >= SPLIT_MIN_BATCH) {  // halves for the two-stream solve: cut at a multiple of 64 instances (whole waves, whole 128-byte lines)
+        p->half_b0[0] = 0;
+        p->half_B[0] = ((p->B / 2) + 63) / 64 * 64;
+        p->half_b0[1] = p->half_B[0];
+        p->half_B[1] = p->B - p->half_B[0];
+        for (int i = 0; i < 2 && up_ok; i++) {
+            DevDesc hd = p->hdesc;
+            hd.B = p->half_B[i];
+            up_ok = dalloc(p, &p->ddesc_half[i], 1) == 0 &&
+                    hipMemcpyAsync(p->ddesc_half[i], &hd, sizeof(DevDesc), hipMemcpyHostToDevice, c->stream) == hipSuccess &&
+                    hipStreamSynchronize(c->stream) == hipSuccess;  // hd is a stack copy
+        }
+    }
+    if (!up_ok || hipStreamSynchronize(c->stream) != hipSuccess) {
         ilqr_problem_destroy(p);
         return fail(c, "descriptor upload failed");
     }
@@ -508,7 +537,23 @@ static int path_choice() {
     return (e && !std::strcmp(e, "v1")) ? 1 : 2;
 }
 
-static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double penalty, double scaling, int line_search, int early_stop) {
+// The buffer table of one half of a split problem: every per-instance array is [..][Bp] with the instance innermost, so a half is the
+// same table with the base pointers moved by its first instance (gain records: by whole records) and its own descriptor (B = its size).
+static Bufs half_bufs(const ilqr_problem* p, int half) {
+    Bufs v = p->bufs;
+    const size_t o = (size_t)p->half_b0[half];
+    v.desc = p->ddesc_half[half];
+    for (int i = 0; i < 2; i++) { v.X[i] += o; v.U[i] += o; }
+    v.U0 += o; v.q0 += o; v.dq0 += o; v.kp_tg += o;
+    v.KD += o * (size_t)p->dims.n_u * kd_rowp(p->dims.n_x);
+    v.cost += o; v.alpha += o; v.cur += o; v.active += o; v.iters += o; v.status += o; v.kpd += o; v.pend += o; v.pred += o;
+    v.lsc += o; v.dun += o; v.kpdev += o; v.kpx += o; v.dunA += o;
+    if (v.cost_trace) { v.cost_trace += o; v.alpha_trace += o; }
+    if (v.lambda) { v.lambda += o; v.Is += o; }
+    return v;
+}
+
+static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double penalty0, double scaling, int line_search, int early_stop) {
     if (!p) return 1;
     ilqr_ctx* c = p->ctx;
     if (!p->has_state || !p->has_controls) return fail(c, "set_init_state and set_controls must be called before a solve");
@@ -528,71 +573,119 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
     const bool bwd_si = (path != 1) && backward_si_supported(kind, nd, al, p->bufs.m, p->bufs.per_step, p->con_state_only);
     const bool bwd_mfma = (path != 1) && !bwd_si && backward_mfma_supported(kind, nd, al, p->bufs.m);  // wave per instance, f64 matrix cores
     const bool fused = bwd_si && fwd_wave;  // the sweep applies the previous line search's winner itself (ilqr_kernels_coop.hip)
+
+    // ---- one or two independent halves ("lanes" of the launch schedule).  Instances never interact, so the halves of a large batch are
+    // two complete solves on two streams; the second one starts one sweep later, so that its latency-bound sweep runs under the other
+    // half's bandwidth-bound forward pass.  Results do not depend on the split (bit for bit: tests/test_gpu_fullsize.py).  With
+    // per-launch profiling on the problem runs unsplit on the context's stream: the event marks time one kernel at a time.
+    struct Half { Bufs bufs; int B; hipStream_t st; };
+    Half hv[2];
+    int nh = 1;
+    // Measured (rocprofv3 kernel trace, B = 4096): it pays for the wave-per-instance MFMA sweep (C4: 60.3 -> 51.7 ms per solve; 4096 one-wave
+    // workgroups on 3072 wave slots otherwise leave a one-third-full second round), not for the single-integrator pipeline (C3: the forward
+    // pass slows from 0.125 to 0.24 ms and k_kp_derivs from 0.017 to 0.08-0.14 ms when they share the SIMDs with the other half's sweep:
+    // 0.53 ms per iteration against 0.49 unsplit).
+    const bool split = coop && bwd_mfma && !c->profile && p->ddesc_half[0] && nb_iter > 0;
+    if (split) {
+        for (int i = 0; i < 2; i++) {
+            if (!c->half_stream[i]) HIPCHK(c, hipStreamCreateWithFlags(&c->half_stream[i], hipStreamNonBlocking));
+            if (!c->ev_half_done[i]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_half_done[i], hipEventDisableTiming));
+        }
+        if (!c->ev_begin) HIPCHK(c, hipEventCreateWithFlags(&c->ev_begin, hipEventDisableTiming));
+        if (!c->ev_stagger) HIPCHK(c, hipEventCreateWithFlags(&c->ev_stagger, hipEventDisableTiming));
+        HIPCHK(c, hipEventRecord(c->ev_begin, c->stream));  // inputs (and the trace fill) are ordered on the caller's stream
+        nh = 2;
+        for (int i = 0; i < 2; i++) {
+            HIPCHK(c, hipStreamWaitEvent(c->half_stream[i], c->ev_begin, 0));
+            hv[i].bufs = half_bufs(p, i); hv[i].B = p->half_B[i]; hv[i].st = c->half_stream[i];
+        }
+    } else {
+        hv[0].bufs = p->bufs; hv[0].B = p->B; hv[0].st = c->stream;
+    }
+
     FwdArgs f;
     std::memset(&f, 0, sizeof(f));
-    f.line_search = line_search; f.early_stop = early_stop; f.nb_iter = nb_iter; f.penalty_roll = penalty; f.n_alpha = n_alpha; f.al = al ? 1 : 0; f.n_kp = p->desc.n_kp;
+    f.line_search = line_search; f.early_stop = early_stop; f.nb_iter = nb_iter; f.penalty_roll = penalty0; f.n_alpha = n_alpha; f.al = al ? 1 : 0; f.n_kp = p->desc.n_kp;
     f.fused = fused ? 1 : 0;
     for (int k = 0; k < p->desc.n_kp; k++) f.kp_ext |= p->desc.kp_dist[k] | p->desc.kp_has_frame[k] | p->desc.kp_has_Ru[k] | p->desc.kp_joint[k];
-    {
+    for (int h = 0; h < nh; h++) {
+        const Bufs& bf = hv[h].bufs;
+        const int B = hv[h].B;
+        hipStream_t st = hv[h].st;
         ProfScope ps(c, ILQR_PROF_ROLLOUT);
         if (path != 1 && init_lti_supported(kind, nd)) {
-            launch_init_lti(kind, nd, p->bufs, p->B, c->stream);
+            launch_init_lti(kind, nd, bf, B, st);
             if (al && !fused) {  // active-set weights of the initial trajectory: I_k = penalty * (g<0 && lambda==0 ? 0 : 1)
                 f.it = -1; f.do_update = 0;
-                launch_solver_v2(kind, nd, KER_AL_UPDATE, al, p->bufs, p->B, p->T, c->stream, f);
+                launch_solver_v2(kind, nd, KER_AL_UPDATE, al, bf, B, p->T, st, f);
             }
         } else {
-            launch_solver(kind, nd, KER_INIT, al, p->bufs, p->B, c->stream, f);
+            launch_solver(kind, nd, KER_INIT, al, bf, B, st, f);
         }
     }
     HIPCHK(c, hipGetLastError());
+    double penalty = penalty0;
     SweepArgs sw;
     sw.pen_in = penalty; sw.pen_update_prev = penalty; sw.do_update_prev = 0;
     for (int it = 0; it < nb_iter; it++) {
-        {
-            {   // l_x, l_xx at the keypoint steps (FK, log map, J'QJ) for every sweep: none of them holds keypoint code
-                ProfScope ps(c, ILQR_PROF_OTHER);
-                launch_solver(kind, nd, KER_KP_DERIVS, al, p->bufs, p->B, c->stream, f);
-            }
-            ProfScope ps(c, ILQR_PROF_BACKWARD);
-            if (bwd_si) launch_backward_si_coop(al, fused, p->bufs, p->B, c->stream, sw);
-            else if (bwd_mfma) launch_backward_mfma(kind, nd, al, p->bufs, p->B, c->stream);
-            else launch_solver(kind, nd, KER_BACKWARD, al, p->bufs, p->B, c->stream, f);
-        }
-        f.it = it;
-        f.penalty_roll = penalty;  // I_k is stored pre-multiplied by the penalty current at rollout time (AL-ILQR.cpp:190)
-        f.do_update = al && ((it + 1) % lag == 0);
-        if (f.do_update) penalty *= scaling;  // multipliers use the UPDATED penalty (AL-ILQR.cpp:203-205)
-        f.penalty_update = penalty;
-        sw.pen_in = f.penalty_roll; sw.pen_update_prev = f.penalty_update; sw.do_update_prev = f.do_update;  // for the next sweep
-        if (coop) {
+        FwdArgs fi = f;
+        fi.it = it;
+        fi.penalty_roll = penalty;  // I_k is stored pre-multiplied by the penalty current at rollout time (AL-ILQR.cpp:190)
+        fi.do_update = al && ((it + 1) % lag == 0);
+        if (fi.do_update) penalty *= scaling;  // multipliers use the UPDATED penalty (AL-ILQR.cpp:203-205)
+        fi.penalty_update = penalty;
+        for (int h = 0; h < nh; h++) {
+            const Bufs& bf = hv[h].bufs;
+            const int B = hv[h].B;
+            hipStream_t st = hv[h].st;
+            if (split && it == 0 && h == 1) HIPCHK(c, hipStreamWaitEvent(st, c->ev_stagger, 0));  // one sweep behind the first half
             {
-                ProfScope ps(c, ILQR_PROF_FORWARD);
-                if (fwd_wave) launch_forward_wave(kind, p->bufs, p->B, c->stream, f);
-                else if (fwd_lin) launch_forward_lin(nd, KER_FWD_SPEC, p->bufs, p->B, p->T, c->stream, f);
-                else launch_solver_v2(kind, nd, KER_FWD_SPEC, al, p->bufs, p->B, p->T, c->stream, f);
-            }
-            if (fwd_wave) {  // winner applied, AL bookkeeping and buffer flip in one pass over the trajectory -- or by the next sweep (fused)
-                if (!fused || it == nb_iter - 1) {
-                    ProfScope ps(c, ILQR_PROF_APPLY);
-                    launch_apply_wave(kind, p->bufs, p->B, p->T, c->stream, f);
+                {   // l_x, l_xx at the keypoint steps (FK, log map, J'QJ) for every sweep: none of them holds keypoint code
+                    ProfScope ps(c, ILQR_PROF_OTHER);
+                    launch_solver(kind, nd, KER_KP_DERIVS, al, bf, B, st, fi);
                 }
-            } else if (fwd_lin) {  // the cost pass writes no trajectory: the winner is always re-rolled
-                ProfScope ps(c, ILQR_PROF_APPLY);
-                launch_forward_lin(nd, KER_FWD_APPLY, p->bufs, p->B, p->T, c->stream, f);
-            } else if (line_search) {  // time systems: re-roll of the winner where the speculated step size lost, 8 lanes per instance
-                ProfScope ps(c, ILQR_PROF_APPLY);
-                launch_apply_rows_tm(kind, nd, p->bufs, p->B, c->stream, f);
+                ProfScope ps(c, ILQR_PROF_BACKWARD);
+                if (bwd_si) launch_backward_si_coop(al, fused, bf, B, st, sw);
+                else if (bwd_mfma) launch_backward_mfma(kind, nd, al, bf, B, st);
+                else launch_solver(kind, nd, KER_BACKWARD, al, bf, B, st, fi);
             }
-            if (al && !fwd_wave) {  // active-set weights of the accepted trajectory (+ multiplier update every `lag` iterations)
-                ProfScope ps(c, ILQR_PROF_OTHER);
-                launch_solver_v2(kind, nd, KER_AL_UPDATE, al, p->bufs, p->B, p->T, c->stream, f);
+            if (split && it == 0 && h == 0) HIPCHK(c, hipEventRecord(c->ev_stagger, st));
+            if (coop) {
+                {
+                    ProfScope ps(c, ILQR_PROF_FORWARD);
+                    if (fwd_wave) launch_forward_wave(kind, bf, B, st, fi);
+                    else if (fwd_lin) launch_forward_lin(nd, KER_FWD_SPEC, bf, B, p->T, st, fi);
+                    else launch_solver_v2(kind, nd, KER_FWD_SPEC, al, bf, B, p->T, st, fi);
+                }
+                if (fwd_wave) {  // winner applied, AL bookkeeping and buffer flip in one pass over the trajectory -- or by the next sweep (fused)
+                    if (!fused || it == nb_iter - 1) {
+                        ProfScope ps(c, ILQR_PROF_APPLY);
+                        launch_apply_wave(kind, bf, B, p->T, st, fi);
+                    }
+                } else if (fwd_lin) {  // the cost pass writes no trajectory: the winner is always re-rolled
+                    ProfScope ps(c, ILQR_PROF_APPLY);
+                    launch_forward_lin(nd, KER_FWD_APPLY, bf, B, p->T, st, fi);
+                } else if (line_search) {  // time systems: re-roll of the winner where the speculated step size lost, 8 lanes per instance
+                    ProfScope ps(c, ILQR_PROF_APPLY);
+                    launch_apply_rows_tm(kind, nd, bf, B, st, fi);
+                }
+                if (al && !fwd_wave) {  // active-set weights of the accepted trajectory (+ multiplier update every `lag` iterations)
+                    ProfScope ps(c, ILQR_PROF_OTHER);
+                    launch_solver_v2(kind, nd, KER_AL_UPDATE, al, bf, B, p->T, st, fi);
+                }
+            } else {
+                ProfScope ps(c, ILQR_PROF_FORWARD);
+                launch_solver(kind, nd, KER_FORWARD, al, bf, B, st, fi);
             }
-        } else {
-            ProfScope ps(c, ILQR_PROF_FORWARD);
-            launch_solver(kind, nd, KER_FORWARD, al, p->bufs, p->B, c->stream, f);
         }
+        sw.pen_in = fi.penalty_roll; sw.pen_update_prev = fi.penalty_update; sw.do_update_prev = fi.do_update;  // for the next sweep
         HIPCHK(c, hipGetLastError());
+    }
+    if (split) {  // the caller's stream continues when both halves are done
+        for (int i = 0; i < 2; i++) {
+            HIPCHK(c, hipEventRecord(c->ev_half_done[i], c->half_stream[i]));
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_half_done[i], 0));
+        }
     }
     prof_mark(c, -1);
     return 0;

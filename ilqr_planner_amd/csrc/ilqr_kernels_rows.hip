@@ -326,7 +326,8 @@ __global__ __launch_bounds__(64) void k_apply_rows_tm(Bufs a, FwdArgs f) {
         ring[slot][ROWP] = *pXq;
         if (ND == 2) ring[slot][ROWP + 1] = *pXd;
         ring[slot][ROWP + ND] = *pU;
-        const size_t adv = (k < T - 2) ? 1 : 0;  // uniform
+        const size_t adv = (k < T - 2 && inst_ok) ? 1 : 0;  // lanes of instances with nothing pending keep re-reading their first
+                                                            // record: cache hits instead of a second pass over their gains in HBM
         pK += adv * sK_; pXq += adv * sX_; pXd += adv * sX_; pU += adv * sU_;
     };
     UNR for (int q = 0; q < PF; q++) { fetch(q, q); __builtin_amdgcn_sched_barrier(0); }

@@ -26,8 +26,8 @@ void launch_forward_lin(int, int, const Bufs&, int, int, hipStream_t, const FwdA
 void launch_init_lti(int, int, const Bufs&, int, hipStream_t) { refuse("k_init_roll_lti"); }
 void launch_forward_wave(int, const Bufs&, int, hipStream_t, const FwdArgs&) { refuse("k_forward_wg"); }
 void launch_apply_wave(int, const Bufs&, int, int, hipStream_t, const FwdArgs&) { refuse("k_apply"); }
-int batchwide_solve(BatchWideState&, const DevDesc&, Bufs&, int, int, const double*, int, int, int, bool, hipStream_t, std::string&) { refuse("batchwide_solve"); }
+int batchwide_solve(BatchWideState&, const DevDesc&, Bufs&, int, int, const double*, int, int, int, bool, hipStream_t, std::string&, const ProfHook&) { refuse("batchwide_solve"); }
 void batchwide_free(BatchWideState&) {}
-int batchcp_solve(BatchCPState&, const DevDesc&, Bufs&, int, int, int, int, const double*, int, int, int, hipStream_t, std::string&) { refuse("batchcp_solve"); }
+int batchcp_solve(BatchCPState&, const DevDesc&, Bufs&, int, int, int, int, const double*, int, int, int, hipStream_t, std::string&, const ProfHook&) { refuse("batchcp_solve"); }
 void batchcp_free(BatchCPState&) {}
 }  // namespace ilqr
