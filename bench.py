@@ -231,6 +231,8 @@ def main():
     ap.add_argument("--iters", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU-baseline sample and the parity report (profiler runs)")
     ap.add_argument("--gather-trajectories", action="store_true", help="N>1: also gather X / U to rank 0 every step")
+    ap.add_argument("--no-split", action="store_true", help="one kernel at a time on one stream (ilqr_ctx_set_split(0)): for rocprofv3 runs whose "
+                    "per-kernel durations are to be compared with the roofline block")
     args = ap.parse_args()
 
     import numpy as np
@@ -262,6 +264,8 @@ def main():
     assert hi - lo == B
     nb_iter = int(args.iters or cfg["nb_iter"])
     ctx = capi.Context(local_rank)
+    if args.no_split:
+        ctx.set_split(False)
     stream = torch.cuda.Stream()  # a real (non-null) stream shared by the library's launches and torch's collectives
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)

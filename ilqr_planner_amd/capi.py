@@ -29,7 +29,7 @@ EXPORTS = [
     "ilqr_problem_get_iters", "ilqr_problem_get_status", "ilqr_problem_get_lambda", "ilqr_problem_get_trace",
     "ilqr_problem_get_X_dev", "ilqr_problem_get_U_dev", "ilqr_problem_get_cost_dev", "ilqr_fk_batch",
     "ilqr_profile_enable", "ilqr_profile_reset", "ilqr_profile_get", "ilqr_chain_from_urdf", "ilqr_urdf_last_error",
-    "ilqr_problem_reset_multipliers", "ilqr_problem_warm_start", "ilqr_problem_track", "ilqr_problem_track_dev",
+    "ilqr_problem_reset_multipliers", "ilqr_problem_warm_start", "ilqr_problem_track", "ilqr_problem_track_dev", "ilqr_ctx_set_split",
 ]
 
 
@@ -107,6 +107,7 @@ def load():
     L.ilqr_ctx_destroy.restype = None
     L.ilqr_ctx_set_stream.argtypes = [vp, vp]
     L.ilqr_ctx_synchronize.argtypes = [vp]
+    L.ilqr_ctx_set_split.argtypes = [vp, C.c_int]
     L.ilqr_problem_create.argtypes = [vp, C.POINTER(ProblemDesc), C.c_int, C.POINTER(vp)]
     L.ilqr_problem_destroy.argtypes = [vp]
     L.ilqr_problem_destroy.restype = None
@@ -257,6 +258,10 @@ class Context:
 
     def synchronize(self):
         self.check(self.L.ilqr_ctx_synchronize(self.h))
+
+    def set_split(self, on: bool):
+        """Two-stream solve of large batches on / off (ilqr_ctx_set_split); off = one kernel at a time, for profiler runs."""
+        self.check(self.L.ilqr_ctx_set_split(self.h, int(bool(on))))
 
     def profile(self, on: bool):
         self.check(self.L.ilqr_profile_enable(self.h, int(on)))

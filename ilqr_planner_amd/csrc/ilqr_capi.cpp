@@ -27,6 +27,7 @@ struct ilqr_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     bool profile = false;
+    bool split = true;  // ilqr_ctx_set_split
     double prof_ms[ILQR_PROF_COUNT] = {0, 0, 0, 0, 0};
     int prof_n[ILQR_PROF_COUNT] = {0, 0, 0, 0, 0};
     struct Pending { hipEvent_t a, b; int which; };
@@ -147,6 +148,12 @@ extern "C" const char* ilqr_last_error(const ilqr_ctx* c) { return c ? c->err.c_
 extern "C" int ilqr_ctx_set_stream(ilqr_ctx* c, void* s) {
     if (!c) return 1;
     c->stream = s ? (hipStream_t)s : c->own_stream;
+    return 0;
+}
+
+extern "C" int ilqr_ctx_set_split(ilqr_ctx* c, int on) {
+    if (!c) return 1;
+    c->split = on != 0;
     return 0;
 }
 
@@ -585,7 +592,7 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
     // workgroups on 3072 wave slots otherwise leave a one-third-full second round), not for the single-integrator pipeline (C3: the forward
     // pass slows from 0.125 to 0.24 ms and k_kp_derivs from 0.017 to 0.08-0.14 ms when they share the SIMDs with the other half's sweep:
     // 0.53 ms per iteration against 0.49 unsplit).
-    const bool split = coop && bwd_mfma && !c->profile && p->ddesc_half[0] && nb_iter > 0;
+    const bool split = coop && bwd_mfma && c->split && !c->profile && p->ddesc_half[0] && nb_iter > 0;
     if (split) {
         for (int i = 0; i < 2; i++) {
             if (!c->half_stream[i]) HIPCHK(c, hipStreamCreateWithFlags(&c->half_stream[i], hipStreamNonBlocking));

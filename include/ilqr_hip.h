@@ -148,6 +148,10 @@ const char* ilqr_last_error(const ilqr_ctx* ctx);
 /* run everything on the caller's hipStream_t (e.g. torch's current stream); NULL = the context's own stream */
 int ilqr_ctx_set_stream(ilqr_ctx* ctx, void* hip_stream);
 int ilqr_ctx_synchronize(ilqr_ctx* ctx);
+/* Large batches of the systems that use the wave-per-instance MFMA sweep are solved as two halves on two internal streams, joined to the
+ * context's stream by events (instances are independent: results do not depend on it).  on = 0 keeps every launch on the context's
+ * stream, one kernel at a time -- what a profiler run wants.  Default: on.  (No reference counterpart: the reference has no batch.) */
+int ilqr_ctx_set_split(ilqr_ctx* ctx, int on);
 const char* ilqr_version(void);
 
 /* ---- a batch of B instances of one System ---------------------------------------------------------------- */
