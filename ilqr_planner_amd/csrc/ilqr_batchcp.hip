@@ -388,7 +388,10 @@ __global__ __launch_bounds__(64) void k_cpl_init(Bufs a, CPArgs c) {
     constexpr int NX = S::NX, NU = S::NU, IPB = 64 / KWP;
     static_assert(64 % KWP == 0, "KWP lanes per instance");
     const DevDesc& d = *a.desc;
-    const int q = threadIdx.x % KWP, b = blockIdx.x * IPB + threadIdx.x / KWP;
+    // XCD-aware tile index: a wave covers 64 / KWP consecutive instances = 32 bytes of every 128-byte line of U0, so four waves share each
+    // line; dealt round-robin over the XCDs (tile = blockIdx) they sat on four different L2s and every line of U0 came from HBM four
+    // times (FETCH_SIZE: 739 MB for 183 MB of controls)
+    const int q = threadIdx.x % KWP, b = xcd_tile() * IPB + threadIdx.x / KWP;
     if (b >= d.B) return;
     const int Bp = d.Bp, T = d.T;
     double x[NX], xp[NX], u[NU], xn[NX], g0 = 0;
@@ -599,6 +602,7 @@ static int run_cpl(BatchCPState& st, const DevDesc& h, Bufs& bufs, const std::ve
             }
         }
     };
+    if (!st.cpl_tables) {
     std::vector<std::vector<double>> Wt(T, std::vector<double>(NX * KWP, 0.0)), Wr(T, std::vector<double>(NX * KWP, 0.0));
     for (int i = 0; i + 1 < T; i++) { Wt[i + 1] = Wt[i]; advance(Wt[i + 1], i); }
     for (int i = 1; i + 1 < T; i++) { Wr[i + 1] = Wr[i]; advance(Wr[i + 1], i); }
@@ -623,6 +627,8 @@ static int run_cpl(BatchCPState& st, const DevDesc& h, Bufs& bufs, const std::ve
         err = "ilqr_solve_batch_cp: sensitivity upload failed";
         return 1;
     }
+    st.cpl_tables = true;
+    }  // tables
     const dim3 grid((B + LPB - 1) / LPB), block(LPB);
     const size_t lds_h = sizeof(double) * KWP * KWP * LPB;
     if (hipFuncSetAttribute((const void*)k_cp_solve<S, KWP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h) != hipSuccess) {
@@ -636,7 +642,7 @@ static int run_cpl(BatchCPState& st, const DevDesc& h, Bufs& bufs, const std::ve
     c.wref = st.wref;
     const bool wave_solve = !(std::getenv("ILQR_CP_SOLVE") && !std::strcmp(std::getenv("ILQR_CP_SOLVE"), "lane"));  // cross-check: lane per instance
     ph(ILQR_PROF_ROLLOUT);   // rollout of u0, its keypoint states and the quadratic forms of the control cost (walks the horizon)
-    hipLaunchKernelGGL((k_cpl_init<S, KWP>), dim3((B + 64 / KWP - 1) / (64 / KWP)), dim3(64), 0, stream, bufs, c);
+    hipLaunchKernelGGL((k_cpl_init<S, KWP>), dim3(grid_x8((B + 64 / KWP - 1) / (64 / KWP))), dim3(64), 0, stream, bufs, c);
     if (nkp > 0) hipLaunchKernelGGL(k_cpl_bcast, dim3((B + 255) / 256, nkp * NX * KWP), dim3(256), 0, stream, st.wref, st.Wkp, nkp * NX * KWP, B, h.Bp);
     for (int it = 0; it < nb_iter; it++) {
         c.it = it;
@@ -674,12 +680,21 @@ int batchcp_solve(BatchCPState& st, const DevDesc& h, Bufs& bufs, int nx, int nu
                   cp_alloc(st, &st.c00, (size_t)Bp, stream) && cp_alloc(st, &st.xbk, (size_t)nkp * 2 * nx * Bp, stream);
         if (!ok) { batchcp_free(st); err = "ilqr_solve_batch_cp: hipMalloc failed"; return 1; }
         st.KWP = KWP; st.nkp = nkp; st.nx = nx; st.Bp = Bp; st.rows = rows;
+        st.sig.clear(); st.psi_host.clear(); st.cpl_tables = false;
     }
     st.Kw = Kw;
+    // the shared tables depend on PSI and on (horizon, dt, R, keypoint steps): rebuilt only when one of them changes
+    std::vector<double> sig = {(double)T, (double)nu, (double)nx, (double)Kw, h.dt, (double)h.kind, (double)h.nd, (double)h.n_kp};
+    for (int i = 0; i < nu; i++) sig.push_back(h.R_diag[i]);
+    for (int i = 0; i < h.n_kp; i++) sig.push_back((double)h.kp_t[i]);
+    const bool same = st.sig == sig && st.psi_host.size() == (size_t)rows * Kw &&
+                      std::memcmp(st.psi_host.data(), psi_host, sizeof(double) * (size_t)rows * Kw) == 0;
+    if (!same) { st.cpl_tables = false; st.sig = sig; st.psi_host.assign(psi_host, psi_host + (size_t)rows * Kw); }
     // PSI padded to KWP columns; H0 = PSI' R PSI with 1 on the padded diagonal (keeps H non-singular, dw_pad = 0)
     std::vector<double> psip((size_t)rows * KWP, 0.0), H0((size_t)KWP * KWP, 0.0);
     for (int k = 0; k < rows; k++)
         for (int q = 0; q < Kw; q++) psip[(size_t)k * KWP + q] = psi_host[(size_t)k * Kw + q];
+    if (!same) {
     for (int a_ = 0; a_ < Kw; a_++)
         for (int b_ = 0; b_ < Kw; b_++) {
             double s = 0;
@@ -691,8 +706,10 @@ int batchcp_solve(BatchCPState& st, const DevDesc& h, Bufs& bufs, int nx, int nu
         hipMemcpyAsync(st.H0, H0.data(), H0.size() * sizeof(double), hipMemcpyHostToDevice, stream) != hipSuccess ||
         hipStreamSynchronize(stream) != hipSuccess) {
         err = "ilqr_solve_batch_cp: PSI upload failed";
+        st.sig.clear();
         return 1;
     }
+    }  // !same
     static const bool general = std::getenv("ILQR_CP") && !std::strcmp(std::getenv("ILQR_CP"), "general");  // cross-check path
     if (KWP == 32) {  // wider bases on the time systems: the same kernels with 32 lanes per instance
         if (h.kind == 3) return run_cp<Sys<3, 1>, 32>(st, h, bufs, nb_iter, early_stop, stream, err, ph);

@@ -38,6 +38,11 @@ struct BatchCPState {
     double* c00 = nullptr;  // [Bp]               u0' R u0
     double* xbk = nullptr;  // [n_kp][2][NX][Bp]  x_t, x_{t-1} of the rollout of u0
     std::vector<void*> allocs;
+    // what the shared tables on the device (psi, H0, wt, wref, pp) were built from: a solve with the same basis on the same system skips
+    // the host-side table construction, the uploads and their stream synchronisations (0.25 ms of a 3.3 ms C5 solve)
+    std::vector<double> psi_host;
+    std::vector<double> sig;
+    bool cpl_tables = false;  // wt / wref / pp of the coefficient-space path are valid for (psi_host, sig)
 };
 
 // Args shared by the three kernels
