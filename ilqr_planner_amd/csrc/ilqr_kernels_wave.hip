@@ -380,45 +380,56 @@ __global__ void k_flip_ran(Bufs a) {
 // task cost at the keypoints (one lane per instance) and sets the bookkeeping; the AL weights come from k_al_post.
 template <class S>
 __global__ __launch_bounds__(256) void k_init_roll_lti(Bufs a) {
-    static_assert(S::TM == 0, "constant-dt systems (PosOrn, JointSpace)");
-    constexpr int NX = S::NX, NU = S::NU, ND = S::ND, CH = 8;
+    // One lane per (instance, coordinate): joint i (position and, 2nd order, velocity); for the time systems one more lane per instance
+    // carries the time state, and every lane reads the step's time control (dt = u_last^2, PosOrnTimePlannerSys.cpp:154-155).
+    constexpr int NX = S::NX, NU = S::NU, ND = S::ND, TM = S::TM, CH = 8;
     const DevDesc& d = *a.desc;
     const int b = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
     if (b >= d.B) return;
     const int Bp = d.Bp, T = d.T;
-    const double dt = d.dt, hdt2 = dt * dt / 2, pen = d.penalty;
-    const bool lim = d.limits_set != 0;
-    const double mxq = (lim && d.lw[i]) ? d.smax[i] : INFINITY, mnq = (lim && d.lw[i]) ? d.smin[i] : -INFINITY;
-    const double mxv = (lim && ND == 2 && d.lw[DOF + i]) ? d.smax[DOF + i] : INFINITY, mnv = (lim && ND == 2 && d.lw[DOF + i]) ? d.smin[DOF + i] : -INFINITY;
+    const bool isT = TM && i == DOF;   // the time-state lane
+    const int ij = isT ? 0 : i;        // joint index (clamped for the time lane)
+    const int xrow = isT ? NX - 1 : i, urow = isT ? NU - 1 : i;
+    const double pen = d.penalty;
+    const bool lim = d.limits_set != 0 && !isT;
+    const double mxq = (lim && d.lw[ij]) ? d.smax[ij] : INFINITY, mnq = (lim && d.lw[ij]) ? d.smin[ij] : -INFINITY;
+    const double mxv = (lim && ND == 2 && d.lw[DOF + ij]) ? d.smax[DOF + ij] : INFINITY, mnv = (lim && ND == 2 && d.lw[DOF + ij]) ? d.smin[DOF + ij] : -INFINITY;
     auto lcost = [&](double v, double mx, double mn) { const double q = fmax(v - mx, 0.0) + fmax(mn - v, 0.0); return q * pen * q; };
-    double q = AT(a.q0, i, b), v = (ND == 2) ? AT(a.dq0, i, b) : 0.0, cost = 0;
+    double q = isT ? 0.0 : AT(a.q0, ij, b), v = (ND == 2 && !isT) ? AT(a.dq0, ij, b) : 0.0, cost = 0;
     const double* __restrict__ U0 = a.U0;
     double* __restrict__ X = a.X[0];
     double* __restrict__ U = a.U[0];
     for (int k0 = 0; k0 < T - 1; k0 += CH) {
-        double u[CH];
-        UNR for (int j = 0; j < CH; j++) u[j] = AT(U0, (k0 + j < T - 1 ? k0 + j : T - 2) * NU + i, b);
+        double u[CH], us[CH];
+        UNR for (int j = 0; j < CH; j++) {
+            const int kk = (k0 + j < T - 1 ? k0 + j : T - 2);
+            u[j] = AT(U0, kk * NU + urow, b);
+            us[j] = TM ? AT(U0, kk * NU + NU - 1, b) : 0.0;
+        }
         UNR for (int j = 0; j < CH; j++) {
             const int k = k0 + j;
             if (k >= T - 1) break;
-            AT(X, k * NX + i, b) = q;
-            if (ND == 2) AT(X, k * NX + DOF + i, b) = v;
-            AT(U, k * NU + i, b) = u[j];
+            const double dt = TM ? us[j] * us[j] : d.dt;
+            AT(X, k * NX + xrow, b) = q;
+            if (ND == 2 && !isT) AT(X, k * NX + DOF + ij, b) = v;
+            AT(U, k * NU + urow, b) = u[j];
             cost += lcost(q, mxq, mnq);
             if (ND == 2) cost += lcost(v, mxv, mnv);
-            if (ND == 1) {
-                q = q + (dt * u[j] + dt * dt / 2 * 0.0);  // dyn_step, same expression
+            if (isT) {
+                q = q + dt;                                 // dyn_step, same expressions
+            } else if (ND == 1) {
+                q = q + (dt * u[j] + dt * dt / 2 * 0.0);
             } else {
-                q = q + (dt * v + hdt2 * u[j]);
+                q = q + (dt * v + dt * dt / 2 * u[j]);
                 v = v + dt * u[j];
             }
         }
     }
-    AT(X, (T - 1) * NX + i, b) = q;
-    if (ND == 2) AT(X, (T - 1) * NX + DOF + i, b) = v;
+    AT(X, (T - 1) * NX + xrow, b) = q;
+    if (ND == 2 && !isT) AT(X, (T - 1) * NX + DOF + ij, b) = v;
     cost += lcost(q, mxq, mnq);
     if (ND == 2) cost += lcost(v, mxv, mnv);
-    AT(a.lsc, i, b) = cost;  // scratch: limit cost of coordinate i over the horizon
+    if (!isT) AT(a.lsc, ij, b) = cost;  // scratch: limit cost of coordinate i over the horizon
 }
 
 template <class S>
@@ -448,17 +459,20 @@ __global__ __launch_bounds__(64) void k_init_finish(Bufs a) {
     a.status[b] = isfinite(cost) ? 0 : 1;
 }
 
-bool init_lti_supported(int kind, int nd) {
-    return (kind == 0 && (nd == 1 || nd == 2)) || (kind == 2 && nd == 1);
+bool init_lti_supported(int kind, int nd) {  // every system: the coordinates integrate independently given the step's dt
+    return ((kind == 0 || kind == 1) && (nd == 1 || nd == 2)) || ((kind == 2 || kind == 3) && nd == 1);
 }
 
 template <class S>
 static void launch_init_lti_sys(const Bufs& a, int B, hipStream_t st) {
-    hipLaunchKernelGGL((k_init_roll_lti<S>), dim3((B + 255) / 256, DOF), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_init_roll_lti<S>), dim3((B + 255) / 256, DOF + S::TM), dim3(256), 0, st, a);
     hipLaunchKernelGGL((k_init_finish<S>), dim3((B + 63) / 64), dim3(64), 0, st, a);
 }
 void launch_init_lti(int kind, int nd, const Bufs& a, int B, hipStream_t st) {
     if (kind == 2) launch_init_lti_sys<Sys<2, 1>>(a, B, st);
+    else if (kind == 3) launch_init_lti_sys<Sys<3, 1>>(a, B, st);
+    else if (kind == 1 && nd == 1) launch_init_lti_sys<Sys<1, 1>>(a, B, st);
+    else if (kind == 1) launch_init_lti_sys<Sys<1, 2>>(a, B, st);
     else if (nd == 1) launch_init_lti_sys<Sys<0, 1>>(a, B, st);
     else launch_init_lti_sys<Sys<0, 2>>(a, B, st);
 }
