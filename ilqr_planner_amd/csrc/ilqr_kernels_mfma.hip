@@ -15,6 +15,12 @@
 // the few vectors.  The time column of B needs dot products with P and B^T P: they are split over all 64 lanes and reduced
 // with lane shuffles instead of being walked by the 16 lanes that own the results.
 // MI355X runs f64 MFMA at the vector rate -- the gain is the removed LDS traffic, not FLOPs.
+//
+// Register budget: 2 waves per SIMD (256 VGPRs; 238 used).  The step is written branch-free where a choice depends on the lane (loads hoisted
+// out of the conditions with clamped indices, `fma(mask ? dt : 0, up, own)` instead of `mask ? dt * up + own : own`): the first version spent
+// ~1500 of its ~4000 instructions per three steps on saveexec / cbranch / restore sequences around ~110 divergent regions per step.  That costs
+// registers -- at the former budget of 168 VGPRs (3 waves per SIMD) the branch-free form spills 78 of them into the loop and is 2x slower, at
+// 256 it is 30 % faster than the branchy one (B = 2048: 985 -> 684 us, B = 4096: 1881 -> 1351 us; profiles/r02_batch_scan.txt).
 #include <cstdlib>
 #include <cstring>
 
@@ -56,7 +62,7 @@ __device__ __forceinline__ double cross_rows_sum(double v) {  // sum over lanes 
 __device__ __forceinline__ double wave_sum_m(double v) { return cross_rows_sum(row16_sum(v)); }
 
 template <class S, bool AL>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_backward_mfma(Bufs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_backward_mfma(Bufs a) {
     constexpr int NX = S::NX, NU = S::NU, ND = S::ND, TM = S::TM;
     constexpr int PS = 18;  // row stride of sP / sBtP (doubles): rows 16-byte aligned, starts in distinct banks
     constexpr int TS = 10;  // row stride of the NU x NU matrices
@@ -138,17 +144,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             }
             kpi--;
             kp_next = (kpi >= 0) ? d.kp_t[kpi] : -1;
-        } else if (lim_on) {
-            UNR for (int r = 0; r < 4; r++)
-                if (dgl[r]) {
-                    const double xi = sx[pi[r]];
-                    if (colA) {  // l_x_i = -L q,  q = limit - x
-                        if (xi > lmx[r]) lq[r] = -pen * (lmx[r] - xi);
-                        else if (xi < lmn[r]) lq[r] = -pen * (lmn[r] - xi);
-                    } else if (xi > lmx[r] || xi < lmn[r]) {
-                        lq[r] = pen_xx;
-                    }
-                }
+        } else if (lim_on) {  // uniform.  Lane-dependent choices below are selects on values, never branches: a divergent branch costs a
+            // saveexec / cbranch / restore sequence, and this kernel was spending more instructions on those than on arithmetic
+            UNR for (int r = 0; r < 4; r++) {
+                const double xi = sx[pi[r]], mx = lmx[r], mn = lmn[r];
+                const bool hi = xi > mx, lo = xi < mn;
+                const double lxv = hi ? -pen * (mx - xi) : (lo ? -pen * (mn - xi) : 0.0);  // l_x_i = -L q,  q = limit - x
+                const double lxxv = (hi || lo) ? pen_xx : 0.0;
+                lq[r] = dgl[r] ? (colA ? lxv : lxxv) : 0.0;
+            }
         }
     };
     {   // terminal values: P = l_xx(x_{T-1}), p = l_x(x_{T-1})
@@ -200,36 +204,40 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         const double dt = TM ? dts * dts : d.dt;
         const double hdt2 = dt * dt / 2;
         const double c1 = (ND == 1) ? dt : hdt2, c2 = dt;  // B = [c1 I ; c2 I] on the joint block
-        if (TM) {
-            double bcv = 0;
-            if (l < DOF) {
-                if (ND == 1) bcv = 2 * dts * su[l];
-                else {
-                    const double dqn = sx[DOF + l] + dt * su[l];  // velocity AFTER the step (PosOrnTimePlannerSys.cpp:176)
-                    bcv = 2 * dts * dqn + 2 * dts * dts * dts * su[l];
-                }
-            } else if (ND == 2 && l < 2 * DOF) {
-                bcv = 2 * dts * su[l - DOF];
-            } else if (l == NX - 1) {
-                bcv = 2 * dts;
+        if (TM) {  // lane l < n_x forms bc_l (PosOrnTimePlannerSys.cpp:161-162,176); all candidates are computed, the lane's one is selected
+            const int lj = l < DOF ? l : ((ND == 2 && l < 2 * DOF) ? l - DOF : 0);
+            const double sul = su[lj];
+            double bcv;
+            if (ND == 1) {
+                bcv = 2 * dts * sul;
+            } else {
+                const double dqn = sx[DOF + lj] + dt * sul;  // velocity AFTER the step
+                const double bq = 2 * dts * dqn + 2 * dts * dts * dts * sul;
+                bcv = (l < DOF) ? bq : 2 * dts * sul;
             }
+            bcv = (l == NX - 1) ? 2 * dts : ((l < NX - 1) ? bcv : 0.0);
             *wbc = bcv;
         }
         double lq[4];
         stage_terms(k, lq);
         LDS_ORDER();
-        auto atp = [&](int i, int cc) { return is_vrow(i) ? dt * sP[i - DOF][cc] + sP[i][cc] : sP[i][cc]; };  // (A^T P)[i][cc]
+        auto atp = [&](int i, int cc) {  // (A^T P)[i][cc]; both loads unconditional (the row above a velocity row, else the row itself)
+            const bool vr = is_vrow(i);
+            const double own = sP[i][cc], up = sP[vr ? i - DOF : i][cc];
+            return fma(vr ? dt : 0.0, up, own);  // (+ 0 x up on the other rows: exact)
+        };
         // ---- 2. time column: wT[j] = sum_q bc_q P[q][j] (row NU-1 of B^T P), wA[i] = sum_q (A^T P)[i][q] bc_q (column NU-1 of
         //         Qxu), bp = bc . p; every lane adds 4 terms of the sum for column / row c16, lanes c16 + 16 h' hold the rest
         double wT = 0, wA = 0, bp = 0;
         if (TM) {
             UNR for (int t = 0; t < 4; t++) {
-                const int q = h + 4 * t;
-                if (q < NX) {
-                    const double bq = sbc[q];
-                    wT += bq * (colA ? sp[q] : sP[q][cj]);  // the affine column carries p: its "column sum" is bc . p
-                    wA += atp(cj, q) * bq;
-                }
+                const int q0 = h + 4 * t;
+                const bool qok = q0 < NX;
+                const int q = qok ? q0 : 0;
+                const double bq = qok ? sbc[q] : 0.0;           // rows beyond n_x add 0
+                const double pq = sp[q], Pq = sP[q][cj];
+                wT += bq * (colA ? pq : Pq);                     // the affine column carries p: its "column sum" is bc . p
+                wA += atp(cj, q) * bq;
             }
             wT = cross_rows_sum(wT);
             wA = cross_rows_sum(wA);
@@ -239,8 +247,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         double btp[2];
         UNR for (int r = 0; r < 2; r++) {
             const int i = ui[r];
-            if (TM && i == NU - 1) btp[r] = wT;
-            else btp[r] = (ND == 1) ? dt * sP[i][cj] : hdt2 * sP[i][cj] + dt * sP[DOF + i][cj];
+            const bool trow = TM && i == NU - 1;   // the time control's row of B^T P is the reduced column sum
+            const int ij = trow ? 0 : i;
+            const double joint = (ND == 1) ? dt * sP[ij][cj] : hdt2 * sP[ij][cj] + dt * sP[DOF + ij][cj];
+            btp[r] = trow ? wT : joint;
             *wBtP[r] = btp[r];
         }
         LDS_ORDER();
@@ -248,40 +258,47 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         double qux[2], qxu[2];
         UNR for (int r = 0; r < 2; r++) {
             const int i = ui[r];
-            double v = 0, w = 0;
-            if (colS) {
-                v = is_vrow(cj) ? sBtP[i][cj - DOF] * dt + btp[r] : btp[r];
-                if (TM && i == NU - 1) w = wA;
-                else w = (ND == 1) ? atp(cj, i) * dt : atp(cj, i) * hdt2 + atp(cj, DOF + i) * dt;
-            } else if (colA) {  // Qu_i = R_i u_i + (B^T p)_i
-                const double btpp = (TM && i == NU - 1) ? bp : ((ND == 1) ? dt * sp[i] : hdt2 * sp[i] + dt * sp[DOF + i]);
-                v = d.R_diag[i] * su[i] + btpp;
-            }
+            const bool trow = TM && i == NU - 1;
+            const int ij = trow ? 0 : i;
+            const bool vr = is_vrow(cj);
+            // state column: Qux[i][c] = (B^T P A)[i][c],  Qxu[c][i] = (A^T P B)[c][i]
+            const double left = sBtP[i][vr ? cj - DOF : cj];
+            const double vS = fma(vr ? dt : 0.0, left, btp[r]);
+            const double a1 = atp(cj, ij), a2 = (ND == 2) ? atp(cj, DOF + ij) : 0.0;
+            const double wJ = (ND == 1) ? a1 * dt : a1 * hdt2 + a2 * dt;
+            const double wS = trow ? wA : wJ;
+            // affine column: Qu_i = R_i u_i + (B^T p)_i
+            const double pj = (ND == 1) ? dt * sp[ij] : hdt2 * sp[ij] + dt * sp[DOF + ij];
+            const double vA = d.R_diag[i] * su[i] + (trow ? bp : pj);
+            const double v = colS ? vS : (colA ? vA : 0.0);
             qux[r] = uv[r] ? v : 0.0;
-            qxu[r] = (uv[r] && colS) ? w : 0.0;
+            qxu[r] = (uv[r] && colS) ? wS : 0.0;
         }
         double quu;
         {
             double tot = 0;
             if (TM) {  // column NU-1: sum_q BtP[qi][q] bc_q; the 8 lanes of a row add two terms each (q = qj, qj + 8), DPP butterfly
+                const bool second = qj + 8 < NX;
+                const int q2 = second ? qj + 8 : qj;
                 double part = sBtP[qi][qj] * sbc[qj];
-                if (qj + 8 < NX) part += sBtP[qi][qj + 8] * sbc[qj + 8];
+                const double part2 = sBtP[qi][q2] * sbc[q2];
+                part += second ? part2 : 0.0;
                 tot = oct_sum_m(qv ? part : 0.0);
             }
-            if (TM && qj == NU - 1) quu = tot;
-            else quu = (ND == 1) ? sBtP[qi][qj] * dt : sBtP[qi][qj] * hdt2 + sBtP[qi][DOF + qj] * dt;
-            if (qi == qj) quu = d.R_diag[qi] + quu;
+            const int qjj = (TM && qj == NU - 1) ? 0 : qj;
+            const double joint = (ND == 1) ? sBtP[qi][qjj] * dt : sBtP[qi][qjj] * hdt2 + sBtP[qi][DOF + qjj] * dt;
+            quu = (TM && qj == NU - 1) ? tot : joint;
+            quu = (qi == qj) ? d.R_diag[qi] + quu : quu;
         }
         double qxx[4];
         UNR for (int r = 0; r < 4; r++) {
             const int i = pi[r];
-            double v = 0;
-            if (colS) {
-                const double t0 = atp(i, cj);
-                v = is_vrow(cj) ? atp(i, cj - DOF) * dt + t0 : t0;
-            } else if (colA) {  // Qx_i = l_x_i + (A^T p)_i
-                v = is_vrow(i) ? dt * sp[i - DOF] + sp[i] : sp[i];
-            }
+            const bool vc = is_vrow(cj), vi = is_vrow(i);
+            const double t0 = atp(i, cj), t1 = atp(i, vc ? cj - DOF : cj);
+            const double vS = fma(vc ? dt : 0.0, t1, t0);                      // state column: (A^T P A)[i][c]
+            const double pown = sp[i], pup = sp[vi ? i - DOF : i];
+            const double vA = fma(vi ? dt : 0.0, pup, pown);                   // affine column: Qx_i = l_x_i + (A^T p)_i
+            const double v = colS ? vS : (colA ? vA : 0.0);
             qxx[r] = pv[r] ? lq[r] + v : 0.0;
         }
         if (AL) {
