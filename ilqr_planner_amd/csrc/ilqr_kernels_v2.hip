@@ -51,15 +51,16 @@ struct LimRegs {
         pen_xx = d.pen_xx;
         UNR for (int i = 0; i < NX; i++) { smax[i] = d.smax[i]; smin[i] = d.smin[i]; lw[i] = d.lw[i]; }
     }
+    // q' L q of inspectJointLimit, branch-free: the distance beyond the bound is max(x - max, 0) + max(min - x, 0), and (-q) pen (-q) == q pen q
+    // bit for bit (a NaN state adds 0 in both forms).  The nested `if (x > max) .. else if (x < min)` compiled to two exec-mask regions per
+    // coordinate -- 19 instructions each, a quarter of k_forward_tile's step.
     __device__ __forceinline__ double cost(const double* x) const {
         double a = 0;
         if (on) {
             UNR for (int i = 0; i < NX; i++) {
-                if (lw[i] != 0) {
-                    double qv = 0, L = 0;
-                    if (x[i] > smax[i]) { qv = smax[i] - x[i]; L = penalty; }
-                    else if (x[i] < smin[i]) { qv = smin[i] - x[i]; L = penalty; }
-                    a += qv * L * qv;
+                if (lw[i] != 0) {  // uniform
+                    const double q = fmax(x[i] - smax[i], 0.0) + fmax(smin[i] - x[i], 0.0);
+                    a += q * penalty * q;
                 }
             }
         }
@@ -84,6 +85,8 @@ __global__ __launch_bounds__(FT_TI * 16) void k_forward_tile(Bufs a, FwdArgs f) 
     __shared__ double s_in[2][NC][TI];
     __shared__ double s_out[2][NO][TI];
     __shared__ int s_wr[TI];
+    __shared__ double s_dump[NT];  // where loader slots without a destination (padding of a gain record, lanes beyond the last row) write:
+                                   // an unconditional ds_write instead of one exec-mask region per slot and step
 
     const DevDesc& d = *a.desc;
     const int tid = threadIdx.x, il = tid >> 4, ai = tid & 15;
@@ -139,6 +142,7 @@ __global__ __launch_bounds__(FT_TI * 16) void k_forward_tile(Bufs a, FwdArgs f) 
         const int inst = flc / RS, w = flc % RS, i = w / ROWP, jj = w % ROWP;
         goff[q] = flc;
         gdst[q] = !in ? -1 : (jj < NX ? (i * NX + jj) * TI + inst : (jj == NX ? (NK + i) * TI + inst : -1));
+
     }
     const double* xptr[NLX];
     size_t xstep[NLX];
@@ -151,17 +155,21 @@ __global__ __launch_bounds__(FT_TI * 16) void k_forward_tile(Bufs a, FwdArgs f) 
         else { xptr[j] = Uc + (size_t)(cc - NX) * Bp + lb; xstep[j] = (size_t)NU * Bp; xkmax[j] = T - 2; }
         xdst[j] = in ? (NK + NU + cc) * TI + li : -1;
     }
+    // running pointers: load_step is called for k = 0, 1, 2, ... in order; a pointer stops at its array's last timestep (steps beyond the end
+    // re-read it).  One 64-bit add per pointer and step instead of a 64-bit multiply-add chain per address.
+    const double* gp[NLG];
+    UNR for (int q = 0; q < NLG; q++) gp[q] = gbase + goff[q];
     auto load_step = [&](int k, double* r) {
-        const int kg = k < T - 1 ? k : T - 2;
-        UNR for (int q = 0; q < NLG; q++) r[q] = gbase[(size_t)kg * gstep + goff[q]];
-        UNR for (int j = 0; j < NLX; j++) r[NLG + j] = xptr[j][(size_t)(k < xkmax[j] ? k : xkmax[j]) * xstep[j]];
+        UNR for (int q = 0; q < NLG; q++) r[q] = *gp[q];
+        UNR for (int j = 0; j < NLX; j++) r[NLG + j] = *xptr[j];
+        const size_t gadv = (k < T - 2) ? gstep : 0;  // uniform
+        UNR for (int q = 0; q < NLG; q++) gp[q] += gadv;
+        UNR for (int j = 0; j < NLX; j++) xptr[j] += (k < xkmax[j]) ? xstep[j] : 0;
     };
     auto stage_step = [&](int buf, const double* r) {
         double* dst = &s_in[buf][0][0];
-        UNR for (int q = 0; q < NLG; q++)
-            if (gdst[q] >= 0) dst[gdst[q]] = r[q];
-        UNR for (int j = 0; j < NLX; j++)
-            if (xdst[j] >= 0) dst[xdst[j]] = r[NLG + j];
+        UNR for (int q = 0; q < NLG; q++) *(gdst[q] >= 0 ? dst + gdst[q] : &s_dump[tid]) = r[q];
+        UNR for (int j = 0; j < NLX; j++) *(xdst[j] >= 0 ? dst + xdst[j] : &s_dump[tid]) = r[NLG + j];
     };
     // output stage: thread t stores component (t >> 4) + 16 j of instance t & 15
     constexpr int NST = (NO + 15) / 16;
