@@ -148,9 +148,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             // saveexec / cbranch / restore sequence, and this kernel was spending more instructions on those than on arithmetic
             UNR for (int r = 0; r < 4; r++) {
                 const double xi = sx[pi[r]], mx = lmx[r], mn = lmn[r];
-                const bool hi = xi > mx, lo = xi < mn;
-                const double lxv = hi ? -pen * (mx - xi) : (lo ? -pen * (mn - xi) : 0.0);  // l_x_i = -L q,  q = limit - x
-                const double lxxv = (hi || lo) ? pen_xx : 0.0;
+                const double over = fmax(xi - mx, 0.0), under = fmax(mn - xi, 0.0);   // at most one of them is non-zero
+                const double lxv = pen * over - pen * under;                             // l_x_i = -L q, q = limit - x (same bits as -pen (max - x))
+                const double lxxv = (over + under > 0.0) ? pen_xx : 0.0;
                 lq[r] = dgl[r] ? (colA ? lxv : lxxv) : 0.0;
             }
         }
@@ -330,7 +330,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             UNR for (int c = 0; c < NU; c++) {
                 const double aic = sS[qi][c], acj = sS[c][qj], acc = sS[c][c];
                 LDS_ORDER();
-                const double r = rcp_nr_m(acc);
+                const double r = rcp_nr_m(acc);  // (forming the next pivot's reciprocal early, as k_backward_si_coop does, costs three more broadcast reads
+                                                 // per pivot here and measured 3 % slower)
                 const double tt = aic * r;
                 double val = fma(-tt, acj, sv);
                 if (qj == c) val = tt;
@@ -344,8 +345,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         // ---- 6. K~ = Quu_inv Qux~ ; T1~ = Quu K~ + Qux~ ; P~' = [Qxx | Qx] + K~^T T1~ + Qxu K~   (f64 matrix cores)
         const bool rowU = c16 < NU;
         const int cu = rowU ? c16 : 0;
-        const double sa0 = rowU ? sS[cu][h] : 0.0, sa1 = rowU ? sS[cu][4 + h] : 0.0;       // A operand: Quu_inv[c16][4c + h]
-        const double qa0 = rowU ? sQuu[cu][h] : 0.0, qa1 = rowU ? sQuu[cu][4 + h] : 0.0;   // A operand: Quu[c16][4c + h]
+        const double mU = rowU ? 1.0 : 0.0;  // (a factor, not a select: a select of a load is compiled as an exec-mask region around the load)
+        const double sa0 = sS[cu][h] * mU, sa1 = sS[cu][4 + h] * mU;       // A operand: Quu_inv[c16][4c + h]
+        const double qa0 = sQuu[cu][h] * mU, qa1 = sQuu[cu][4 + h] * mU;   // A operand: Quu[c16][4c + h]
         d4_t Kt = {0, 0, 0, 0};
         Kt = __builtin_amdgcn_mfma_f64_16x16x4f64(sa0, qux[0], Kt, 0, 0, 0);
         Kt = __builtin_amdgcn_mfma_f64_16x16x4f64(sa1, qux[1], Kt, 0, 0, 0);
