@@ -5,7 +5,7 @@ TAG=${1:-p}; shift
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
 rm -rf "$OUT"
-ILQR_BENCH_NOPROF=1 rocprofv3 --pmc $1 --output-format csv -d "$OUT" -o run -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline $PROF_ARGS > "$OUT.log" 2>&1
+rocprofv3 --pmc $1 --output-format csv -d "$OUT" -o run -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-split $PROF_ARGS > "$OUT.log" 2>&1
 cd $GRAFT_REPO_ROOT
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
