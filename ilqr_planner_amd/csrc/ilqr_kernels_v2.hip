@@ -44,25 +44,32 @@ struct LimRegs {
     int on;
     double penalty, pen_xx;
     double smax[NX], smin[NX];
-    int lw[NX];
     __device__ __forceinline__ void load(const DevDesc& d) {
         on = d.limits_set;
         penalty = d.penalty;
         pen_xx = d.pen_xx;
-        UNR for (int i = 0; i < NX; i++) { smax[i] = d.smax[i]; smin[i] = d.smin[i]; lw[i] = d.lw[i]; }
+        // an unweighted coordinate gets the bounds (+inf, -inf): its distance beyond them is max(x - inf, 0) + max(-inf - x, 0) = 0 for every x
+        // (NaN and +-inf included: max() drops a NaN operand), so it adds q pen q = +0 -- no test of the weight inside the rollout
+        UNR for (int i = 0; i < NX; i++) {
+            const bool w = d.lw[i] != 0;
+            smax[i] = w ? d.smax[i] : __builtin_inf();
+            smin[i] = w ? d.smin[i] : -__builtin_inf();
+        }
     }
     // q' L q of inspectJointLimit, branch-free: the distance beyond the bound is max(x - max, 0) + max(min - x, 0), and (-q) pen (-q) == q pen q
     // bit for bit (a NaN state adds 0 in both forms).  The nested `if (x > max) .. else if (x < min)` compiled to two exec-mask regions per
-    // coordinate -- 19 instructions each, a quarter of k_forward_tile's step.
+    // coordinate -- 19 instructions each, a quarter of k_forward_tile's step; a (uniform) test of the weight per coordinate made every coordinate
+    // its own basic block: 7 dependent instructions through the same two temporaries, no overlap between coordinates.  Here the 15 distances
+    // are independent of each other and only the final sum is a chain.
     __device__ __forceinline__ double cost(const double* x) const {
         double a = 0;
         if (on) {
+            double q[NX], t[NX];
             UNR for (int i = 0; i < NX; i++) {
-                if (lw[i] != 0) {  // uniform
-                    const double q = fmax(x[i] - smax[i], 0.0) + fmax(smin[i] - x[i], 0.0);
-                    a += q * penalty * q;
-                }
+                q[i] = fmax(x[i] - smax[i], 0.0) + fmax(smin[i] - x[i], 0.0);
+                t[i] = q[i] * penalty;
             }
+            UNR for (int i = 0; i < NX; i++) a = __builtin_fma(t[i], q[i], a);  // (`a += q * penalty * q` as the compiler contracts it)
         }
         return a;
     }
@@ -80,7 +87,7 @@ __global__ __launch_bounds__(FT_TI * 16) void k_forward_tile(Bufs a, FwdArgs f) 
     constexpr int NX = S::NX, NU = S::NU, NK = NU * NX;
     constexpr int NC = NK + NU + NX + NU;          // doubles per instance-step: K | d | xbar | ubar
     constexpr int NO = NX + NU;                    // doubles written per instance-step: x | u
-    constexpr int PF = 4;                          // prefetch distance in timesteps
+    constexpr int PF = 3;                          // prefetch distance in timesteps
     constexpr int TI = FT_TI, NT = TI * 16;        // instances per workgroup (x 16 step sizes each) and its threads
     __shared__ double s_in[2][NC][TI];
     __shared__ double s_out[2][NO][TI];
@@ -214,15 +221,43 @@ __global__ __launch_bounds__(FT_TI * 16) void k_forward_tile(Bufs a, FwdArgs f) 
                 UNR for (int q = 0; q < NLD; q++) nxt[q] = pre[(j + 1) % PF][q];
                 load_step(k + PF, pre[j]);
                 if (part) {
-                    double u[NU], dx[NX];
-                    UNR for (int i = 0; i < NX; i++) dx[i] = x[i] - s_in[buf][NK + NU + i][il];
+                    // u = ubar + K (x - xbar) + alpha d, two control rows at a time.  The LDS reads of the NEXT two rows are issued before the
+                    // products of the current two and fenced there (sched_barrier): left to itself the compiler issues one ds_read2 two
+                    // instructions ahead of its use -- 60 exposed LDS latencies per step, and a wave is alone on its SIMD here
+                    const double* sb = &s_in[buf][0][il];
+                    auto SI = [&](int c) { return sb[c * TI]; };
+                    double u[NU], dx[NX], xb[NX], kr[2][2][NX], dd[2][2], ub[2][2];
+                    auto rows = [&](int s, int i0) {
+                        UNR for (int r = 0; r < 2; r++) {
+                            if (i0 + r < NU) {
+                                UNR for (int q = 0; q < NX; q++) kr[s][r][q] = SI((i0 + r) * NX + q);
+                                dd[s][r] = SI(NK + i0 + r);
+                                ub[s][r] = SI(NK + NU + NX + i0 + r);
+                            }
+                        }
+                    };
+                    UNR for (int i = 0; i < NX; i++) xb[i] = SI(NK + NU + i);
+                    rows(0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    UNR for (int i = 0; i < NX; i++) dx[i] = x[i] - xb[i];
                     double n2 = 0;
-                    UNR for (int i = 0; i < NU; i++) {
-                        double s = 0;
-                        UNR for (int q = 0; q < NX; q++) s += s_in[buf][i * NX + q][il] * dx[q];
-                        const double du = s + alpha * s_in[buf][NK + i][il];
-                        n2 += du * du;
-                        u[i] = s_in[buf][NK + NU + NX + i][il] + du;
+                    UNR for (int i0 = 0; i0 < NU; i0 += 2) {
+                        const int s = (i0 >> 1) & 1;
+                        if (i0 + 2 < NU) rows(s ^ 1, i0 + 2);
+                        __builtin_amdgcn_sched_barrier(0);
+                        double acc[2] = {0, 0};
+                        UNR for (int q = 0; q < NX; q++) {
+                            UNR for (int r = 0; r < 2; r++)
+                                if (i0 + r < NU) acc[r] += kr[s][r][q] * dx[q];
+                        }
+                        UNR for (int r = 0; r < 2; r++) {
+                            if (i0 + r < NU) {
+                                const double du = acc[r] + alpha * dd[s][r];
+                                n2 += du * du;
+                                u[i0 + r] = ub[s][r] + du;
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                     dun += sqrt(n2);
                     if (writer) {
