@@ -114,6 +114,20 @@ __global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a, SweepArgs sw) {
         Kji[e] = KD_REC(a.KD, Bp, RS, T - 2, bb) + j * ROWP + i;
     }
     const double* rowV = &sA[g][v][0];
+    // sweep operands per pivot c: a_ic, a_jc from the lower triangle (rows are padded: column 9 of row 0 holds the constant -1 the entries
+    // of the pivot row / column read instead, see the sweeps below)
+    const double* pvI[N][EPL];
+    const double* pvJ[N][EPL];
+    double pvM[N][EPL];
+    UNR for (int c = 0; c < N; c++) {
+        UNR for (int e = 0; e < EPL; e++) {
+            const double* neg = &sA[g][0][9];
+            pvI[c][e] = (ei[e] == c) ? neg : ((c <= ei[e]) ? &sA[g][ei[e]][c] : &sA[g][c][ei[e]]);
+            pvJ[c][e] = (ej[e] == c) ? neg : ((c <= ej[e]) ? &sA[g][ej[e]][c] : &sA[g][c][ej[e]]);
+            pvM[c][e] = (ei[e] == c || ej[e] == c) ? 0.0 : 1.0;
+        }
+    }
+    if (l == 0) sA[g][0][9] = -1.0;
     // constraint rows (state part only: checked on the host)
     const int m = a.m;
     double Ai[MRR][EPL], Aj[MRR][EPL], Av[MRR], bbr[MRR], Arow[MRR][N];
@@ -229,8 +243,8 @@ __global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a, SweepArgs sw) {
         UNR for (int c = 0; c < N; c++) {
             double aic[EPL], ajc[EPL];
             UNR for (int e = 0; e < EPL; e++) {
-                aic[e] = *((c <= ei[e]) ? &sA[g][ei[e]][c] : &sA[g][c][ei[e]]);
-                ajc[e] = *((c <= ej[e]) ? &sA[g][ej[e]][c] : &sA[g][c][ej[e]]);
+                aic[e] = *pvI[c][e];
+                ajc[e] = *pvJ[c][e];
             }
             double rn = 0;
             if (c + 1 < N) {  // next pivot after this sweep: a_{c+1,c+1} - a_{c+1,c}^2 / a_cc
@@ -239,11 +253,12 @@ __global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a, SweepArgs sw) {
             }
             LDS_ORDER();
             UNR for (int e = 0; e < EPL; e++) {
+                // ONE expression for all four kinds of entries: the entries of the pivot row / column read -1 for "their" a_ic / a_jc (pvI, pvJ)
+                // and take 0 for their own value (pvM), which turns  s - (a_ic r) a_jc  into  a_ic r  (entry (i, c)),  a_jc r  (entry (c, j))
+                // and  -r  (the pivot), each with the bits of the direct expression.  Three selects per entry and pivot (six v_cndmask)
+                // became one multiplication.
                 const double t = aic[e] * r;
-                double val = fma(-t, ajc[e], s[e]);
-                if (ej[e] == c) val = t;               // entry (i, c), i != c : a_ic / d
-                if (ei[e] == c) val = ajc[e] * r;      // entry (c, j), j != c : a_cj / d
-                if (ei[e] == c && ej[e] == c) val = -r;
+                const double val = fma(-t, ajc[e], s[e] * pvM[c][e]);
                 s[e] = val;
                 if (c + 1 < N) *sAij[e] = val;
             }
