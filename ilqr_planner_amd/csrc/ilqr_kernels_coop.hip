@@ -40,8 +40,8 @@ __device__ __forceinline__ double rcp_nr(double x) {  // 1/x to the last bit: v_
 template <int CTRL>
 __device__ __forceinline__ double dpp64(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, false);  // (every lane has a source in these patterns: no "old" value to keep, no copy)
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double oct_sum(double v) {  // sum over lanes 8m .. 8m+7, result in all eight
@@ -88,8 +88,10 @@ __global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a, SweepArgs sw) {
     const double Rv = d.R_diag[v], Dv = Rv + reg;
     const int lim_on = d.limits_set;
     const double pen = d.penalty, pen_xx = d.pen_xx;
-    const double smax_v = d.smax[v], smin_v = d.smin[v];
+    // bounds with the weight folded in: an unweighted coordinate gets (+inf, -inf), which no x violates (a NaN neither) -- the step below
+    // forms the limit terms by max() arithmetic without testing the weight or the kind of entry
     const int lw_v = d.lw[v];
+    const double smax_v = lw_v != 0 ? d.smax[v] : __builtin_inf(), smin_v = lw_v != 0 ? d.smin[v] : -__builtin_inf();
 
     // entries owned by this lane: n = l + e*LPI (entries beyond 27 shadow entry 0 and never store)
     bool isE[EPL], dg[EPL];
@@ -107,7 +109,9 @@ __global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a, SweepArgs sw) {
         const int j = le - i * (i + 1) / 2;
         ei[e] = i; ej[e] = j; dg[e] = (i == j);
         Di[e] = d.R_diag[i] + reg; Dj[e] = d.R_diag[j] + reg; del[e] = dg[e] ? 1.0 : 0.0;
-        smax_i[e] = d.smax[i]; smin_i[e] = d.smin[i]; lw_i[e] = d.lw[i];
+        lw_i[e] = d.lw[i];
+        const bool we = dg[e] && lw_i[e] != 0;  // l_xx of the limits is diagonal
+        smax_i[e] = we ? d.smax[i] : __builtin_inf(); smin_i[e] = we ? d.smin[i] : -__builtin_inf();
         sAij[e] = &sA[g][i][j]; sAji[e] = &sA[g][j][i];
         rowI[e] = &sA[g][i][0]; rowJ[e] = &sA[g][j][0];
         Kij[e] = KD_REC(a.KD, Bp, RS, T - 2, bb) + i * ROWP + j;
@@ -322,15 +326,14 @@ __global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a, SweepArgs sw) {
             asm volatile("" : "+v"(lx));
             kpi--;
             kp_next = (kpi >= 0) ? d.kp_t[kpi] : -1;
-        } else if (lim_on) {
+        } else if (lim_on) {  // uniform.  inspectJointLimit (System.cpp:121-142) branch-free: the nested tests were five exec-mask regions per step
             UNR for (int e = 0; e < EPL; e++) {
                 const double xi = sV[g][0][ei[e]];
-                if (dg[e] && lw_i[e] != 0 && (xi > smax_i[e] || xi < smin_i[e])) lxx[e] = pen_xx;
+                const double beyond = fmax(xi - smax_i[e], 0.0) + fmax(smin_i[e] - xi, 0.0);
+                lxx[e] = (beyond > 0.0) ? pen_xx : 0.0;
             }
-            if (lw_v != 0) {
-                if (xv > smax_v) lx = -pen * (smax_v - xv);
-                else if (xv < smin_v) lx = -pen * (smin_v - xv);
-            }
+            // l_x = -L q, q = limit - x on the violated side: pen (x - max) above, -pen (min - x) below -- the bits of -pen (max - x), -pen (min - x)
+            lx = pen * fmax(xv - smax_v, 0.0) - pen * fmax(smin_v - xv, 0.0);
         }
         if (MR > 0) {
             UNR for (int rr = 0; rr < MRR; rr++) {
