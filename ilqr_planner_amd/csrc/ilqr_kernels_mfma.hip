@@ -70,6 +70,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     constexpr int MMAX = 16;
     static_assert(NX <= 15 && NU <= 8, "one affine column next to the state, two k-steps of 4");
     __shared__ __attribute__((aligned(16))) double sP[16][PS], sBtP[8][PS], sS[8][TS], sQuu[8][TS];
+    __shared__ double sD[8];  // the diagonal of the matrix under the sweeps (its places in sS hold the constant -1, see there)
     __shared__ __attribute__((aligned(16))) double sx[16], su[8], sbc[16], sp[16], slam[MMAX], sIs[MMAX];
     __shared__ double sDump[64];  // target of the stores of lanes that own nothing: an unconditional ds_write is cheaper than an exec-mask branch
 
@@ -93,6 +94,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (l < 16) { sx[l] = 0; sbc[l] = 0; sp[l] = 0; slam[l] = 0; sIs[l] = 0; }
     if (l < 8) su[l] = 0;
     LDS_ORDER();
+    if (l < 8) { sS[l][l] = -1.0; sD[l] = 0; }
+    LDS_ORDER();
 
     // ---- lane maps
     const bool colS = c16 < NX;      // this lane's column is a state column
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     double* const dump = &sDump[l];
     double* wBtP[2];
     UNR for (int r = 0; r < 2; r++) wBtP[r] = (uv[r] && colS) ? &sBtP[ui[r]][c16] : dump;
-    double* const wS = qv ? &sS[qi][qj] : dump;
+    double* const wS = qv ? ((qi == qj) ? &sD[qi] : &sS[qi][qj]) : dump;
     double* const wQuu = qv ? &sQuu[qi][qj] : dump;
     double* wP[4];
     UNR for (int r = 0; r < 4; r++) wP[r] = (pv[r] && colS) ? &sP[pi[r]][c16] : ((pv[r] && colA) ? &sp[pi[r]] : dump);
@@ -129,6 +132,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         lmx[r] = d.smax[pi[r]];
         lmn[r] = d.smin[pi[r]];
     }
+
+    // control weights of the rows this lane works on: out of the descriptor once (read inside the loop they are a global load and an
+    // s_waitcnt vmcnt(0) per step -- which also waits for the whole prefetch ring)
+    double pvm[NU];  // sweep of pivot c: 0 for the entries of row / column c, 1 elsewhere (below)
+    UNR for (int c = 0; c < NU; c++) pvm[c] = (qi == c || qj == c) ? 0.0 : 1.0;
+    const int cu_ = (c16 < NU) ? c16 : 0;
+    const double* const rdS0 = (cu_ == h) ? &sD[cu_] : &sS[cu_][h];
+    const double* const rdS1 = (cu_ == 4 + h) ? &sD[cu_] : &sS[cu_][4 + h];
+    const double Ru[2] = {d.R_diag[ui[0]], d.R_diag[ui[1]]};
+    const double Rq = d.R_diag[qi];
 
     int kpi = d.n_kp - 1;
     int kp_next = (kpi >= 0) ? d.kp_t[kpi] : -1;
@@ -231,10 +244,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         double wT = 0, wA = 0, bp = 0;
         if (TM) {
             UNR for (int t = 0; t < 4; t++) {
-                const int q0 = h + 4 * t;
-                const bool qok = q0 < NX;
-                const int q = qok ? q0 : 0;
-                const double bq = qok ? sbc[q] : 0.0;           // rows beyond n_x add 0
+                const int q = h + 4 * t;                          // 0..15: the entries beyond n_x of sbc / sp / sP are the zeros of the start
+                const double bq = sbc[q];
                 const double pq = sp[q], Pq = sP[q][cj];
                 wT += bq * (colA ? pq : Pq);                     // the affine column carries p: its "column sum" is bc . p
                 wA += atp(cj, q) * bq;
@@ -269,7 +280,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             const double wS = trow ? wA : wJ;
             // affine column: Qu_i = R_i u_i + (B^T p)_i
             const double pj = (ND == 1) ? dt * sp[ij] : hdt2 * sp[ij] + dt * sp[DOF + ij];
-            const double vA = d.R_diag[i] * su[i] + (trow ? bp : pj);
+            const double vA = Ru[r] * su[i] + (trow ? bp : pj);
             const double v = colS ? vS : (colA ? vA : 0.0);
             qux[r] = uv[r] ? v : 0.0;
             qxu[r] = (uv[r] && colS) ? wS : 0.0;
@@ -288,7 +299,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             const int qjj = (TM && qj == NU - 1) ? 0 : qj;
             const double joint = (ND == 1) ? sBtP[qi][qjj] * dt : sBtP[qi][qjj] * hdt2 + sBtP[qi][DOF + qjj] * dt;
             quu = (TM && qj == NU - 1) ? tot : joint;
-            quu = (qi == qj) ? d.R_diag[qi] + quu : quu;
+            quu = (qi == qj) ? Rq + quu : quu;
         }
         double qxx[4];
         UNR for (int r = 0; r < 4; r++) {
@@ -322,21 +333,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             }
         }
         *wQuu = quu;
-        *wS = quu + ((qi == qj) ? reg : 0.0);
+        const double s0 = quu + ((qi == qj) ? reg : 0.0);
+        *wS = s0;
         LDS_ORDER();
         // ---- 5. symmetric sweeps on Quu + reg I: afterwards sS = -(Quu + reg I)^-1 = Quu_inv of the reference
         {
-            double sv = sS[qi][qj];
+            double sv = s0;
             UNR for (int c = 0; c < NU; c++) {
-                const double aic = sS[qi][c], acj = sS[c][qj], acc = sS[c][c];
+                // ONE expression for all entries (see k_backward_si_coop): the entries of the pivot row / column read the constant -1 for "their"
+                // a_ic / a_cj and take 0 for their own value, which turns  s - (a_ic r) a_cj  into  a_ic r  (column c),  a_cj r  (row c) and
+                // -r  (the pivot) with the bits of the direct expressions -- instead of three selects per pivot.  The -1 sits on the diagonal
+                // of sS for good: the diagonal entries live in sD (written there by their lanes, read from there as the pivot and, below, as
+                // operand of the products), so a_ic = sS[i][c] IS -1 for i = c without any choice of address.
+                const double aic = sS[qi][c];
+                const double acj = sS[c][qj];
+                const double acc = sD[c];
                 LDS_ORDER();
                 const double r = rcp_nr_m(acc);  // (forming the next pivot's reciprocal early, as k_backward_si_coop does, costs three more broadcast reads
                                                  // per pivot here and measured 3 % slower)
                 const double tt = aic * r;
-                double val = fma(-tt, acj, sv);
-                if (qj == c) val = tt;
-                if (qi == c) val = acj * r;
-                if (qi == c && qj == c) val = -r;
+                const double val = fma(-tt, acj, sv * pvm[c]);
                 sv = val;
                 *wS = val;
                 LDS_ORDER();
@@ -346,7 +362,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         const bool rowU = c16 < NU;
         const int cu = rowU ? c16 : 0;
         const double mU = rowU ? 1.0 : 0.0;  // (a factor, not a select: a select of a load is compiled as an exec-mask region around the load)
-        const double sa0 = sS[cu][h] * mU, sa1 = sS[cu][4 + h] * mU;       // A operand: Quu_inv[c16][4c + h]
+        const double sa0 = *rdS0 * mU, sa1 = *rdS1 * mU;                   // A operand: Quu_inv[c16][4c + h] (diagonal entries from sD)
         const double qa0 = sQuu[cu][h] * mU, qa1 = sQuu[cu][4 + h] * mU;   // A operand: Quu[c16][4c + h]
         d4_t Kt = {0, 0, 0, 0};
         Kt = __builtin_amdgcn_mfma_f64_16x16x4f64(sa0, qux[0], Kt, 0, 0, 0);
