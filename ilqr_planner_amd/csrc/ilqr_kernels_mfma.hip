@@ -39,8 +39,8 @@ __device__ __forceinline__ double rcp_nr_m(double x) {  // 1/x to the last bit: 
 template <int CTRL>
 __device__ __forceinline__ double dpp64m(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, false);  // (every lane has a source in these patterns: no "old" value, no copy)
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double oct_sum_m(double v) {  // sum over lanes 8m .. 8m+7, result in all eight
@@ -70,6 +70,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     constexpr int MMAX = 16;
     static_assert(NX <= 15 && NU <= 8, "one affine column next to the state, two k-steps of 4");
     __shared__ __attribute__((aligned(16))) double sP[16][PS], sBtP[8][PS], sS[8][TS], sQuu[8][TS];
+    __shared__ double sLx[16], sLxx[16];  // limit terms of the step (entry 15: constant 0)
     __shared__ double sD[8];  // the diagonal of the matrix under the sweeps (its places in sS hold the constant -1, see there)
     __shared__ __attribute__((aligned(16))) double sx[16], su[8], sbc[16], sp[16], slam[MMAX], sIs[MMAX];
     __shared__ double sDump[64];  // target of the stores of lanes that own nothing: an unconditional ds_write is cheaper than an exec-mask branch
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     for (int i = l; i < 16 * PS; i += 64) (&sP[0][0])[i] = 0;
     for (int i = l; i < 8 * PS; i += 64) (&sBtP[0][0])[i] = 0;
     for (int i = l; i < 8 * TS; i += 64) { (&sS[0][0])[i] = 0; (&sQuu[0][0])[i] = 0; }
-    if (l < 16) { sx[l] = 0; sbc[l] = 0; sp[l] = 0; slam[l] = 0; sIs[l] = 0; }
+    if (l < 16) { sx[l] = 0; sbc[l] = 0; sp[l] = 0; slam[l] = 0; sIs[l] = 0; sLx[l] = 0; sLxx[l] = 0; }
     if (l < 8) su[l] = 0;
     LDS_ORDER();
     if (l < 8) { sS[l][l] = -1.0; sD[l] = 0; }
@@ -123,49 +124,50 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     double* const wu = isU ? &su[vu] : dump;
     double* const wbc = isX ? &sbc[vx] : dump;
 
-    // limit parameters of the entries this lane needs: diagonal P-map entries (l_xx) and the affine column (l_x)
-    bool dgl[4];
-    double lmx[4], lmn[4];
-    UNR for (int r = 0; r < 4; r++) {
-        const bool on = pv[r] && (colA || (colS && pi[r] == c16));
-        dgl[r] = on && d.lw[pi[r]] != 0;
-        lmx[r] = d.smax[pi[r]];
-        lmn[r] = d.smin[pi[r]];
-    }
+    // limit terms (inspectJointLimit, System.cpp:121-142).  Lane i < n_x forms l_x_i and l_xx_ii of ITS coordinate from the x_i it has in a
+    // register (bounds with the weight folded in: (+inf, -inf) where there is none) and drops them into LDS; the P-map picks them up
+    // through per-lane read pointers -- the affine column reads l_x, the diagonal entries l_xx, every other entry a constant zero.  (Each
+    // lane forming the terms of its four P-map rows and selecting the one it needs, if any, was 56 instructions per step.)
+    const bool wl = isX && d.lw[vx] != 0;
+    const double mxl = wl ? d.smax[vx] : __builtin_inf(), mnl = wl ? d.smin[vx] : -__builtin_inf();
+    double* const wLx = isX ? &sLx[vx] : dump;
+    double* const wLxx = isX ? &sLxx[vx] : dump;
+    const double* rdL[4];
+    UNR for (int r = 0; r < 4; r++)
+        rdL[r] = (pv[r] && colA) ? &sLx[pi[r]] : ((pv[r] && colS && pi[r] == c16) ? &sLxx[pi[r]] : &sLxx[15]);
 
-    // control weights of the rows this lane works on: out of the descriptor once (read inside the loop they are a global load and an
-    // s_waitcnt vmcnt(0) per step -- which also waits for the whole prefetch ring)
     double pvm[NU];  // sweep of pivot c: 0 for the entries of row / column c, 1 elsewhere (below)
     UNR for (int c = 0; c < NU; c++) pvm[c] = (qi == c || qj == c) ? 0.0 : 1.0;
     const int cu_ = (c16 < NU) ? c16 : 0;
     const double* const rdS0 = (cu_ == h) ? &sD[cu_] : &sS[cu_][h];
     const double* const rdS1 = (cu_ == 4 + h) ? &sD[cu_] : &sS[cu_][4 + h];
+    // control weights of the rows this lane works on: out of the descriptor once (read inside the loop they are a global load and an
+    // s_waitcnt vmcnt(0) per step -- which also waits for the whole prefetch ring)
     const double Ru[2] = {d.R_diag[ui[0]], d.R_diag[ui[1]]};
     const double Rq = d.R_diag[qi];
 
     int kpi = d.n_kp - 1;
     int kp_next = (kpi >= 0) ? d.kp_t[kpi] : -1;
     const size_t kpd_stride = (size_t)(NX + NX * NX) * Bp;
-    // [l_xx | l_x] of step k in the P-map (needs sx); keypoint steps come from k_kp_derivs (limits included)
-    auto stage_terms = [&](int k, double* lq) {
-        UNR for (int r = 0; r < 4; r++) lq[r] = 0;
+    // [l_xx | l_x] of step k in the P-map (xk: this lane's coordinate of x_k); keypoint steps come from k_kp_derivs (limits included)
+    auto stage_terms = [&](int k, double xk, double* lq) {
         if (k == kp_next) {  // uniform
             const double* src = a.kpd + (size_t)kpi * kpd_stride;
             UNR for (int r = 0; r < 4; r++) {
+                lq[r] = 0;
                 if (pv[r] && colS) lq[r] = AT(src, NX + pi[r] * NX + c16, b);
                 if (pv[r] && colA) lq[r] = AT(src, pi[r], b);
             }
             kpi--;
             kp_next = (kpi >= 0) ? d.kp_t[kpi] : -1;
-        } else if (lim_on) {  // uniform.  Lane-dependent choices below are selects on values, never branches: a divergent branch costs a
-            // saveexec / cbranch / restore sequence, and this kernel was spending more instructions on those than on arithmetic
-            UNR for (int r = 0; r < 4; r++) {
-                const double xi = sx[pi[r]], mx = lmx[r], mn = lmn[r];
-                const double over = fmax(xi - mx, 0.0), under = fmax(mn - xi, 0.0);   // at most one of them is non-zero
-                const double lxv = pen * over - pen * under;                             // l_x_i = -L q, q = limit - x (same bits as -pen (max - x))
-                const double lxxv = (over + under > 0.0) ? pen_xx : 0.0;
-                lq[r] = dgl[r] ? (colA ? lxv : lxxv) : 0.0;
-            }
+        } else if (lim_on) {  // uniform
+            const double over = fmax(xk - mxl, 0.0), under = fmax(mnl - xk, 0.0);   // at most one of them is non-zero
+            *wLx = pen * over - pen * under;                      // l_x_i = -L q, q = limit - x (same bits as -pen (max - x))
+            *wLxx = (over + under > 0.0) ? pen_xx : 0.0;
+            LDS_ORDER();
+            UNR for (int r = 0; r < 4; r++) lq[r] = *rdL[r];
+        } else {
+            UNR for (int r = 0; r < 4; r++) lq[r] = 0;
         }
     };
     {   // terminal values: P = l_xx(x_{T-1}), p = l_x(x_{T-1})
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if (isX) sx[vx] = xv;
         LDS_ORDER();
         double lq[4];
-        stage_terms(T - 1, lq);
+        stage_terms(T - 1, xv, lq);
         UNR for (int r = 0; r < 4; r++) {
             if (pv[r] && colS) sP[pi[r]][c16] = lq[r];
             if (pv[r] && colA) sp[pi[r]] = lq[r];
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             *wbc = bcv;
         }
         double lq[4];
-        stage_terms(k, lq);
+        stage_terms(k, xv, lq);
         LDS_ORDER();
         auto atp = [&](int i, int cc) {  // (A^T P)[i][cc]; both loads unconditional (the row above a velocity row, else the row itself)
             const bool vr = is_vrow(i);

@@ -29,8 +29,8 @@ namespace ilqr {
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);  // old = src: every lane is written, no zero-fill moves
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, false);  // every lane is written: no "old" operand, no copy
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
 // sum over the 4 lanes of a quad, result in all 4 (quad_perm [1,0,3,2] then [2,3,0,1])
