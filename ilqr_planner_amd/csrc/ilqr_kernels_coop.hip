@@ -325,7 +325,7 @@ __global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a, SweepArgs sw) {
             UNR for (int e = 0; e < EPL; e++) asm volatile("" : "+v"(lxx[e]));
             asm volatile("" : "+v"(lx));
             kpi--;
-            kp_next = (kpi >= 0) ? d.kp_t[kpi] : -1;
+            kp_next = (kpi >= 0) ? __builtin_amdgcn_readfirstlane(d.kp_t[kpi]) : -1;
         } else if (lim_on) {  // uniform.  inspectJointLimit (System.cpp:121-142) branch-free: the nested tests were five exec-mask regions per step
             UNR for (int e = 0; e < EPL; e++) {
                 const double xi = sV[g][0][ei[e]];

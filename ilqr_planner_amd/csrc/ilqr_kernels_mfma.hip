@@ -158,8 +158,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 if (pv[r] && colS) lq[r] = AT(src, NX + pi[r] * NX + c16, b);
                 if (pv[r] && colA) lq[r] = AT(src, pi[r], b);
             }
+            // consume the loads inside the branch: otherwise their wait lands after the join and every step drains vmcnt to 0 (the prefetch ring)
+            UNR for (int r = 0; r < 4; r++) asm volatile("" : "+v"(lq[r]));
             kpi--;
-            kp_next = (kpi >= 0) ? d.kp_t[kpi] : -1;
+            kp_next = (kpi >= 0) ? __builtin_amdgcn_readfirstlane(d.kp_t[kpi]) : -1;  // (into a scalar register HERE: kept in a vector register, the
+                                                                                         // step's `k == kp_next` waits for this load -- and the ring)
         } else if (lim_on) {  // uniform
             const double over = fmax(xk - mxl, 0.0), under = fmax(mnl - xk, 0.0);   // at most one of them is non-zero
             *wLx = pen * over - pen * under;                      // l_x_i = -L q, q = limit - x (same bits as -pen (max - x))

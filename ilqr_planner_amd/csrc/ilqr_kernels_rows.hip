@@ -180,7 +180,7 @@ __global__ __launch_bounds__(64) void k_forward_lin(Bufs a, FwdArgs f) {
                 if (NA > 8 && r0 + 8 < n_alpha) kpc1 += kp_eval(my_alpha1, true);
                 LDS_ORDER();
                 kpi++;
-                kp_next = (kpi < n_kp) ? d.kp_t[kpi] : -1;
+                kp_next = (kpi < n_kp) ? __builtin_amdgcn_readfirstlane(d.kp_t[kpi]) : -1;  // (scalar register: see k_forward_tile)
             }
             // ---- deviation dynamics: dx' = A dx + B du
             if (ND == 1) {

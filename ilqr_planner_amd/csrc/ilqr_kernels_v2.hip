@@ -270,8 +270,6 @@ __global__ __launch_bounds__(FT_TI * 16) void k_forward_tile(Bufs a, FwdArgs f) 
                             UNR for (int i = 0; i < NX; i++) AT(o, i, b) = x[i];
                             UNR for (int i = 0; i < NU; i++) AT(o, NX + i, b) = u[i];
                         }
-                        kpi++;
-                        kp_next = (kpi < n_kp) ? d.kp_t[kpi] : -1;
                     }
                     if (!APPLY) newCost += lim.cost(x);
                     // dynamics step (SimulationInterface.cpp:19-31)
@@ -287,6 +285,10 @@ __global__ __launch_bounds__(FT_TI * 16) void k_forward_tile(Bufs a, FwdArgs f) 
                         }
                     }
                     if (S::TM) x[NX - 1] = x[NX - 1] + dt;
+                }
+                if (k == kp_next) {  // uniform.  The index of the next keypoint step goes into a scalar register here: left in a vector register (and
+                    kpi++;           // updated under `part`), every step's `k == kp_next` waited for that load -- and with it for all but the newest
+                    kp_next = (kpi < n_kp) ? __builtin_amdgcn_readfirstlane(d.kp_t[kpi]) : -1;  // loads of the prefetch ring
                 }
                 stage_step(buf ^ 1, nxt);
                 lds_barrier();
