@@ -77,6 +77,7 @@ void launch_backward_si_coop(bool al, bool fused, const Bufs& a, int B, hipStrea
 bool backward_mfma_supported(int kind, int nd, bool al, int m);
 void launch_backward_mfma(int kind, int nd, bool al, const Bufs& a, int B, hipStream_t st);  // needs KER_KP_DERIVS first
 bool forward_lin_supported(int kind, int nd, int n_alpha);
+void launch_forward_mfma(int kind, int nd, const Bufs& a, int B, hipStream_t st, const FwdArgs& f);  // time systems: all step sizes of an instance as one matrix-core product per step (ilqr_kernels_fwdm.hip)
 void launch_apply_rows_tm(int kind, int nd, const Bufs& a, int B, hipStream_t st, const FwdArgs& f);  // time systems: re-roll of the winner, 8 lanes per instance
 void launch_forward_lin(int nd, int which, const Bufs& a, int B, int T, hipStream_t st, const FwdArgs& f);
 bool forward_wave_supported(int kind, int nd, int n_alpha);

@@ -22,6 +22,7 @@ void launch_solver_v2(int, int, int, bool, const Bufs&, int, int, hipStream_t, c
 void launch_backward_si_coop(bool, bool, const Bufs&, int, hipStream_t, const SweepArgs&) { refuse("k_backward_si_coop"); }
 void launch_backward_mfma(int, int, bool, const Bufs&, int, hipStream_t) { refuse("k_backward_mfma"); }
 void launch_apply_rows_tm(int, int, const Bufs&, int, hipStream_t, const FwdArgs&) { refuse("k_apply_rows_tm"); }
+void launch_forward_mfma(int, int, const Bufs&, int, hipStream_t, const FwdArgs&) { refuse("k_forward_mfma"); }
 void launch_forward_lin(int, int, const Bufs&, int, int, hipStream_t, const FwdArgs&) { refuse("k_forward_lin"); }
 void launch_init_lti(int, int, const Bufs&, int, hipStream_t) { refuse("k_init_roll_lti"); }
 void launch_forward_wave(int, const Bufs&, int, hipStream_t, const FwdArgs&) { refuse("k_forward_wg"); }
