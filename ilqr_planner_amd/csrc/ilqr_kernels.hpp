@@ -27,10 +27,10 @@ struct Bufs {
     double* kpd;    // [n_kp][NX + NX*NX][Bp] l_x | l_xx of the keypoint steps of the current trajectory (k_kp_derivs)
     int* pend;      // [Bp] line-search winner index + 1 still to be applied by the APPLY pass (0 = nothing pending)
     int* pred;      // [Bp] predicted winner index of the next line search (= winner of the previous iteration)
-    double* lsc;    // [16][Bp] limit cost of the alpha = 1 rollout blended to every step size (k_forward_w32 -> k_select)
+    double* lsc;    // [16][Bp] limit cost of the alpha = 1 rollout blended to every step size (k_forward_wg -> k_select)
     double* dun;    // [Bp] sum_k ||du_k(1)|| of that rollout
     double* kpdev;  // [n_kp][NX+NU][Bp] deviation (dx, du) of that rollout at the keypoint steps
-    double* kpx;    // [n_kp][16][NX+NU][Bp] state | control of every alpha's rollout at the keypoint steps (k_forward_tile -> k_select_x)
+    double* kpx;    // [n_kp][16][NX+NU][Bp] state | control of every alpha's rollout at the keypoint steps (k_forward_mfma -> k_select_x)
     double* dunA;   // [16][Bp] sum_k ||du_k|| of every alpha's rollout
     double* cost_trace;   // [nb_iter][Bp] or null
     double* alpha_trace;  // [nb_iter][Bp] or null

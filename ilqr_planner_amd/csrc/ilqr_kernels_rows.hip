@@ -180,7 +180,7 @@ __global__ __launch_bounds__(64) void k_forward_lin(Bufs a, FwdArgs f) {
                 if (NA > 8 && r0 + 8 < n_alpha) kpc1 += kp_eval(my_alpha1, true);
                 LDS_ORDER();
                 kpi++;
-                kp_next = (kpi < n_kp) ? __builtin_amdgcn_readfirstlane(d.kp_t[kpi]) : -1;  // (scalar register: see k_forward_tile)
+                kp_next = (kpi < n_kp) ? __builtin_amdgcn_readfirstlane(d.kp_t[kpi]) : -1;  // (scalar register: see k_forward_mfma)
             }
             // ---- deviation dynamics: dx' = A dx + B du
             if (ND == 1) {
@@ -280,8 +280,7 @@ __global__ void k_flip(Bufs a) {
 }
 
 // Re-roll of the accepted step size for the TIME systems (dt = u_last^2: the closed loop is not linear in alpha, so the winner of
-// k_forward_tile's alpha-parallel pass has to be rolled out again when it was not the speculated one).  k_forward_tile<APPLY>
-// does it with one lane in sixteen; here 8 lanes share an instance: lane r owns control row r and the joint state (q_r, dq_r),
+// the alpha-parallel pass -- k_forward_mfma -- has to be rolled out again when it was not the speculated one).  8 lanes share an instance: lane r owns control row r and the joint state (q_r, dq_r),
 // lane 7 the time control and the time state.  Per step: LDS all-gather of dx (n_x values), 16-term dot product with the lane's
 // gain row (register ring, 16-byte loads), dt = s^2 broadcast from lane 7, dynamics local to the lane.
 template <class S>
@@ -307,30 +306,53 @@ __global__ __launch_bounds__(64) void k_apply_rows_tm(Bufs a, FwdArgs f) {
     const int rj = isT ? 0 : r;     // joint index for the state rows of this lane (clamped for lane 7)
     const double alpha = ldexp(1.0, -((inst_ok ? a.pend[bb] : 1) - 1));
     const int cur = a.cur[bb];
-    const double* pK = a.KD + (size_t)bb * RS + r * ROWP;
     const double* pXq = a.X[cur] + (size_t)(isT ? NX - 1 : rj) * Bp + bb;            // q_r, or t for lane 7
     const double* pXd = a.X[cur] + (size_t)(ND == 2 ? DOF + rj : rj) * Bp + bb;      // dq_r (2nd order)
     const double* pU = a.U[cur] + (size_t)r * Bp + bb;
-    const size_t sK_ = (size_t)Bp * RS, sU_ = (size_t)NU * Bp, sX_ = (size_t)NX * Bp;
+    const size_t sK2_ = (size_t)Bp * RS / 2, sU_ = (size_t)NU * Bp, sX_ = (size_t)NX * Bp;
     double* oXq = a.X[1 - cur] + (size_t)(isT ? NX - 1 : rj) * Bp + bb;
     double* oXd = a.X[1 - cur] + (size_t)(ND == 2 ? DOF + rj : rj) * Bp + bb;
     double* oU = a.U[1 - cur] + (size_t)r * Bp + bb;
 
-    double ring[PF][NLD];
+    // Gain records: the eight records of the wave's instances are 8 RS doubles in one run.  Lane (g, r) needs row r of record g -- loaded
+    // as such (16-byte pieces of a 128-byte row per lane) every load instruction touches 64 different cache lines, and the address unit of
+    // the CU, not the arithmetic, set the pace of a step.  Instead instruction q loads record q with lane l on bytes 16 l .. 16 l + 15 (one
+    // contiguous KiB), the ring keeps those pieces, and the rows are picked out of an LDS image of the step (dropped there a step ahead;
+    // LDS operations of a wave execute in order: no barrier).  Records of instances with nothing pending stay on their first timestep:
+    // cache hits instead of a second pass over their gains in HBM.
+    constexpr int KS = ROWP + 2;    // row stride of the image (bank spread, rows stay 16-byte aligned)
+    __shared__ __attribute__((aligned(16))) double sKi[8][NU * KS];
+    const int b0 = b - g;
+    const bool pk = 2 * lane < RS;
+    const int prow = pk ? (2 * lane) / ROWP : 0, pcol = pk ? (2 * lane) % ROWP : 0;
+    double* const wKi = &sKi[0][prow * KS + pcol];
+    const double* const rKi = &sKi[g][r * KS];
+    const double2* const K0 = reinterpret_cast<const double2*>(a.KD + (size_t)b0 * RS) + (pk ? lane : 0);
+    const double2* Kk = K0;         // records of the step being fetched
+    bool okq[8];
+    UNR for (int q = 0; q < 8; q++) okq[q] = (b0 + q < B) && (a.pend[b0 + q < B ? b0 + q : 0] > 0);  // wave-uniform
+
+    double rk0[PF][8], rk1[PF][8];  // (two scalar arrays: an array of double2 is not split into registers)
+    double ring[PF][ND + 1];
     auto fetch = [&](int slot, int k) {  // unconditional; the pointers stop at the last timestep
-        UNR for (int q = 0; q < ROWP / 2; q++) {
-            const double2 v2 = reinterpret_cast<const double2*>(pK)[q];
-            ring[slot][2 * q] = v2.x;
-            ring[slot][2 * q + 1] = v2.y;
+        UNR for (int q = 0; q < 8; q++) {
+            const double2 v2 = (okq[q] ? Kk : K0)[(size_t)q * (RS / 2)];
+            rk0[slot][q] = v2.x;
+            rk1[slot][q] = v2.y;
         }
-        ring[slot][ROWP] = *pXq;
-        if (ND == 2) ring[slot][ROWP + 1] = *pXd;
-        ring[slot][ROWP + ND] = *pU;
-        const size_t adv = (k < T - 2 && inst_ok) ? 1 : 0;  // lanes of instances with nothing pending keep re-reading their first
-                                                            // record: cache hits instead of a second pass over their gains in HBM
-        pK += adv * sK_; pXq += adv * sX_; pXd += adv * sX_; pU += adv * sU_;
+        ring[slot][0] = *pXq;
+        if (ND == 2) ring[slot][1] = *pXd;
+        ring[slot][ND] = *pU;
+        if (k < T - 2) Kk += sK2_;  // uniform
+        const size_t adv = (k < T - 2 && inst_ok) ? 1 : 0;
+        pXq += adv * sX_; pXd += adv * sX_; pU += adv * sU_;
+    };
+    auto stage = [&](int slot) {  // pieces of ring slot -> image
+        if (pk) { UNR for (int q = 0; q < 8; q++) *reinterpret_cast<double2*>(wKi + q * NU * KS) = make_double2(rk0[slot][q], rk1[slot][q]); }
     };
     UNR for (int q = 0; q < PF; q++) { fetch(q, q); __builtin_amdgcn_sched_barrier(0); }
+    stage(0);
+    LDS_ORDER();
 
     // state of this lane: joint r (q, dq) or, lane 7, the time
     double xq = isT ? 0.0 : AT(a.q0, rj, bb);
@@ -342,8 +364,11 @@ __global__ __launch_bounds__(64) void k_apply_rows_tm(Bufs a, FwdArgs f) {
         UNR for (int jj = 0; jj < PF; jj++) {
             const int k = k0 + jj;
             double Kr[NX];
-            UNR for (int jx = 0; jx < NX; jx++) Kr[jx] = ring[jj][jx];
-            const double dr = ring[jj][NX], xbq = ring[jj][ROWP], xbd = (ND == 2) ? ring[jj][ROWP + 1] : 0.0, ub = ring[jj][ROWP + ND];
+            UNR for (int jx = 0; jx < NX; jx++) Kr[jx] = rKi[jx];  // this lane's gain row of step k
+            const double dr = rKi[NX], xbq = ring[jj][0], xbd = (ND == 2) ? ring[jj][1] : 0.0, ub = ring[jj][ND];
+            LDS_ORDER();
+            stage((jj + 1) % PF);                                   // step k + 1 into the image
+            LDS_ORDER();
             fetch(jj, k + PF);
             if (k >= nsteps) continue;  // uniform; dummy step of the last group
             // ---- all-gather of dx = x - xbar (state order [q(7) | dq(7) | t])

@@ -221,7 +221,7 @@ __global__ __launch_bounds__(FW_IW * 32) void k_forward_wg(Bufs a, FwdArgs f) {
                     }
                     if (rowst) AT(o, NX + r, bb) = du;
                     kpi++;
-                    kp_next = (kpi < n_kp) ? __builtin_amdgcn_readfirstlane(d.kp_t[kpi]) : -1;  // (scalar register: see k_forward_tile)
+                    kp_next = (kpi < n_kp) ? __builtin_amdgcn_readfirstlane(d.kp_t[kpi]) : -1;  // (scalar register: see k_forward_mfma)
                 }
                 // ---- deviation dynamics: dx' = dx + dt du
                 dx0 = dx0 + dt * du0;

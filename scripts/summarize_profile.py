@@ -11,7 +11,7 @@ out, stats_dir, pmc_dirs = sys.argv[1], sys.argv[2], sys.argv[3:]
 lines = []
 
 # kernel -> the category bench.py times it under (ILQR_PROF_*); bench.pmc_traffic reads the pmc[category] lines
-CATEGORY = (("k_backward", "backward"), ("k_forward_wg", "forward"), ("k_forward_tile", "forward"), ("k_forward_lin", "forward"),
+CATEGORY = (("k_backward", "backward"), ("k_forward_wg", "forward"), ("k_forward_mfma", "forward"), ("k_forward_lin", "forward"),
             ("k_select", "forward"), ("k_cpl_linearize", "backward"), ("k_cp_solve", "backward"), ("k_cp_linearize", "backward"),
             ("k_cpl_linesearch", "forward"), ("k_bt_linesearch", "forward"), ("k_cpl_init", "rollout"), ("k_cp_init", "rollout"),
             ("k_init_", "rollout"), ("k_cpl_controls", "apply"), ("k_cp_final", "apply"), ("k_apply", "apply"), ("k_blend", "apply"))
