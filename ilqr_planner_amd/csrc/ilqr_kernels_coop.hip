@@ -9,9 +9,9 @@
 //   lanes 0..6 additionally own component l of the vectors p, x, u, Qu, d
 // The full matrix lives in LDS (rows padded to 64 B) so that any lane can read any row; the inverse is the symmetric
 // sweep operator applied to the 7 pivots in order (a_cc <- -1/a_cc, a_ic <- a_ic/a_cc, a_ij <- a_ij - a_ic a_jc/a_cc;
-// after all pivots the matrix holds -S^-1), one LDS round trip per pivot; S is SPD so no pivoting is needed.  The
-// reciprocal of the NEXT pivot is formed by every lane from two extra broadcast reads while the current update is in
-// flight, which takes the reciprocal chain off the per-pivot critical path.
+// after all pivots the matrix holds -S^-1), one LDS round trip per pivot; S is SPD so no pivoting is needed.  (Forming the
+// reciprocal of the NEXT pivot early from two extra broadcast reads shortened the chain when the launch was thought latency-bound; it
+// is issue-bound at two waves per SIMD, and reading the pivot after the update -- three instructions less per pivot -- measured 2 % faster.)
 // All exchange is wave-local: LDS operations of one wave execute in order, so there is no barrier anywhere.
 //
 // FUSED = true (the sweep follows k_forward_wg + k_select, ilqr_kernels_wave.hip): the acceptance of the previous iteration's line
@@ -243,18 +243,13 @@ __global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a, SweepArgs sw) {
         }
         LDS_ORDER();
         // ---- symmetric sweeps: after the 7 pivots the matrix holds -S^-1
-        double r = rcp_nr(sA[g][0][0]);
         UNR for (int c = 0; c < N; c++) {
             double aic[EPL], ajc[EPL];
             UNR for (int e = 0; e < EPL; e++) {
                 aic[e] = *pvI[c][e];
                 ajc[e] = *pvJ[c][e];
             }
-            double rn = 0;
-            if (c + 1 < N) {  // next pivot after this sweep: a_{c+1,c+1} - a_{c+1,c}^2 / a_cc
-                const double an = sA[g][c + 1][c + 1], anc = sA[g][c + 1][c];
-                rn = rcp_nr(fma(-(anc * r), anc, an));
-            }
+            const double r = rcp_nr(sA[g][c][c]);
             LDS_ORDER();
             UNR for (int e = 0; e < EPL; e++) {
                 // ONE expression for all four kinds of entries: the entries of the pivot row / column read -1 for "their" a_ic / a_jc (pvI, pvJ)
@@ -267,7 +262,6 @@ __global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a, SweepArgs sw) {
                 if (c + 1 < N) *sAij[e] = val;
             }
             LDS_ORDER();
-            r = rn;
         }
         double M[EPL];
         UNR for (int e = 0; e < EPL; e++) {
