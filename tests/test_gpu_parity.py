@@ -236,6 +236,36 @@ def test_al_constraint_shapes(ctx, per_step, with_control_row):
     assert fin.sum() >= B // 2 and np.median(rel[fin]) <= 1e-6, f"median rel err {np.median(rel[fin]):.2e}"
 
 
+@pytest.mark.parametrize("cfg_name,B", [("C4", 7), ("C4t1", 5), ("C1t", 3), ("C4", 1)])
+def test_time_systems_ragged_batches(ctx, cfg_name, B, hip_path):
+    """Batches that fill neither the four-instance waves of the matrix-core line search (k_forward_mfma) nor the eight-instance waves of the
+    re-roll: without line search (alpha stays 1; two iterations against the oracle) and with it (per-instance proof, early stop on)."""
+    from ilqr_planner_amd import workloads
+    from tests import parity_proof as pp
+    from tests.helpers import oracle_system_of_instance
+
+    cfg = workloads.config(cfg_name)
+    desc, inp = workloads.make_batch(ctx, cfg, B=B, seed=21)
+    p = workloads.load_batch(ctx, desc, inp, B)
+    p.solve_recursive(2, False, False)
+    assert np.all(p.alpha() == 1.0) and np.all(p.iters() == 2)
+    cost = p.cost()
+    for i in range(B):
+        s = orc.solve_recursive(oracle_system_of_instance(cfg, inp, i), inp["U0"][i].reshape(-1), 2, False, False)
+        if np.isfinite(s["cost"]) or np.isfinite(cost[i]):
+            assert abs(cost[i] - s["cost"]) <= 1e-8 * max(1e-6, abs(s["cost"])), (i, cost[i], s["cost"])
+    p.close()
+    nb_iter = 8
+    p = workloads.load_batch(ctx, desc, inp, B)
+    workloads.run_solver(p, cfg, nb_iter=nb_iter, early_stop=True)
+    segs = panda_segs()
+    summ, rel, failures = pp.check_batch(p, cfg, inp, nb_iter, True, workloads.run_solver, lambda i: oracle_solve_instance(cfg, inp, i, nb_iter, True, segs),
+                                         always=tuple(range(B)))
+    p.close()
+    print(f"parity[{hip_path}] {cfg_name} B={B}: {summ}")
+    assert not failures and summ["frac_unexplained"] == 0.0, failures[:3]
+
+
 def test_empty_and_ragged_inputs(ctx):
     """nb_iter = 0 (rollout only), batch not a multiple of the wave size, early stop off, line search off."""
     from ilqr_planner_amd import workloads
