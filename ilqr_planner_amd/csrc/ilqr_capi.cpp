@@ -593,6 +593,8 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
     // pass slows from 0.125 to 0.24 ms and k_kp_derivs from 0.017 to 0.08-0.14 ms when they share the SIMDs with the other half's sweep:
     // 0.53 ms per iteration against 0.49 unsplit).
     const bool split = coop && bwd_mfma && c->split && !c->profile && p->ddesc_half[0] && nb_iter > 0;
+    if (!bwd_si && !bwd_mfma && nb_iter > 0 && !p->bufs.ws)  // the generic sweep keeps the matrices of a step in an explicit workspace
+        if (dalloc(p, &p->bufs.ws, (size_t)backward_ws_entries(kind, nd) * p->Bp, false)) return 1;
     if (split) {
         for (int i = 0; i < 2; i++) {
             if (!c->half_stream[i]) HIPCHK(c, hipStreamCreateWithFlags(&c->half_stream[i], hipStreamNonBlocking));

@@ -98,26 +98,27 @@ __global__ __launch_bounds__(64) void k_kp_derivs(Bufs a, int fused) {
     }
 }
 
-// l_x, l_xx of a stage for the generic sweep: at the keypoint steps the values k_kp_derivs stored for the current trajectory (FK, the
-// quaternion log map, frames, dead zones and J'QJ stay out of the sweep: inlined here they made it a 19 000-line kernel at 512 VGPRs
-// with kilobytes of scratch per lane), elsewhere the limit terms; the second limit set on top of either.
+// Backward Riccati sweep (ILQRRecursive.cpp:68-97): writes K_k, d_k for k = T-2..0.  Needs k_kp_derivs first.
+//
+// One lane per instance, the reference's operation order (dense products, partial-pivot LU as Eigen's inverse()).  The matrices of a step
+// -- 1500 doubles for n_x = 15 against the 256 a lane's whole register file holds -- live in an EXPLICIT workspace in global memory
+// (a.ws, entry e of instance b at ws[e Bp + b]: coalesced across the lanes of a wave), walked by plain loops: 60 VGPRs, no scratch, no
+// compiler-managed private segment.  (As local arrays of a fully unrolled kernel they made 512-VGPR code objects with up to 7 KB of scratch per
+// lane, and in round 1 one of them -- then still with the keypoint code inlined -- ended in a memory aperture violation: DESIGN.md 5.5.)
+// The stage derivatives come from k_kp_derivs at the keypoint steps (FK, the quaternion log map, frames, dead zones and J'QJ stay out of
+// the sweep) and are the limit terms elsewhere; the second limit set on top of either.
+#define NOUNR _Pragma("unroll 1")
 template <class S>
-ILQR_DEV void sweep_stage_derivs(const DevDesc& d, const Bufs& a, int b, int kpi, const double* x, double (*lxx)[S::NX], double* lx) {
-    constexpr int NX = S::NX;
-    const int Bp = d.Bp;
-    if (kpi >= 0) {
-        const double* src = a.kpd + (size_t)kpi * (NX + NX * NX) * Bp;
-        UNR for (int i = 0; i < NX; i++) {
-            lx[i] = AT(src, i, b);
-            UNR for (int j = 0; j < NX; j++) lxx[i][j] = AT(src, NX + i * NX + j, b);
-        }
-    } else {
-        stage_derivs<S>(d, a, b, x, -1, lxx, lx);
-    }
-    if (d.lim2) lim2_derivs<S>(d, x, lxx, lx);
+constexpr int backward_ws_doubles() {
+    return 3 * S::NX * S::NX + 5 * S::NU * S::NX + 3 * S::NU * S::NU + 4 * S::NX + 2 * S::NU;
+}
+int backward_ws_entries(int kind, int nd) {
+    if (kind == 2) return backward_ws_doubles<Sys<2, 1>>();
+    if (kind == 3) return backward_ws_doubles<Sys<3, 1>>();
+    if (kind == 0) return nd == 1 ? backward_ws_doubles<Sys<0, 1>>() : backward_ws_doubles<Sys<0, 2>>();
+    return nd == 1 ? backward_ws_doubles<Sys<1, 1>>() : backward_ws_doubles<Sys<1, 2>>();
 }
 
-// Backward Riccati sweep (ILQRRecursive.cpp:68-97): writes K_k, d_k for k = T-2..0.  Needs k_kp_derivs first.
 template <class S, bool AL>
 __global__ __launch_bounds__(64) void k_backward(Bufs a) {
     constexpr int NX = S::NX, NU = S::NU, ND = S::ND, TM = S::TM;
@@ -129,94 +130,137 @@ __global__ __launch_bounds__(64) void k_backward(Bufs a) {
     const int cur = a.cur[b];
     const double* X = a.X[cur];
     const double* U = a.U[cur];
-    double P[NX][NX], p[NX], x[NX], u[NU];
+    // workspace views
+    double* const w = a.ws + b;
+    constexpr int oP = 0, op = oP + NX * NX, oQxx = op + NX, oQx = oQxx + NX * NX, oAtP = oQx + NX, oBtP = oAtP + NX * NX, oQux = oBtP + NU * NX,
+                  oQxu = oQux + NU * NX, oK = oQxu + NX * NU, oKtQ = oK + NU * NX, oQuu = oKtQ + NX * NU, oMr = oQuu + NU * NU, oQi = oMr + NU * NU,
+                  oQu = oQi + NU * NU, odk = oQu + NU, obc = odk + NU, ox = obc + NX, oEnd = ox + NX;
+    static_assert(oEnd == backward_ws_doubles<S>(), "workspace layout");
+#define WS(o, i, j, C) w[(size_t)((o) + (i) * (C) + (j)) * Bp]
+#define WV(o, i) w[(size_t)((o) + (i)) * Bp]
+    // l_xx -> matrix at oM, l_x -> vector at oV for the state at ox (statement for statement stage_derivs / lim2_derivs of ilqr_step.hpp)
+    auto stage_to_ws = [&](int kpi_, int oM, int oV) {
+        if (kpi_ >= 0) {
+            const double* src = a.kpd + (size_t)kpi_ * (NX + NX * NX) * Bp;
+            NOUNR for (int i = 0; i < NX; i++) {
+                WV(oV, i) = AT(src, i, b);
+                NOUNR for (int j = 0; j < NX; j++) WS(oM, i, j, NX) = AT(src, NX + i * NX + j, b);
+            }
+        } else {
+            NOUNR for (int i = 0; i < NX; i++) {
+                double lxi = 0, lxxi = 0;
+                NOUNR for (int j = 0; j < NX; j++) WS(oM, i, j, NX) = 0;
+                if (d.limits_set && d.lw[i] != 0) {
+                    const double xi = WV(ox, i);
+                    double qv = 0, L = 0;
+                    if (xi > d.smax[i]) { qv = d.smax[i] - xi; L = d.penalty; }
+                    else if (xi < d.smin[i]) { qv = d.smin[i] - xi; L = d.penalty; }
+                    lxi += -L * qv;
+                    lxxi += (L != 0.0) ? d.pen_xx : 0.0;
+                }
+                WV(oV, i) = lxi;
+                WS(oM, i, i, NX) = lxxi;
+            }
+        }
+        if (d.lim2) {
+            NOUNR for (int i = 0; i < NX; i++) {
+                if (d.lw2[i] != 0) {
+                    const double xi = WV(ox, i);
+                    double qv = 0, L = 0;
+                    if (xi > d.smax2[i]) { qv = d.smax2[i] - xi; L = d.penalty2; }
+                    else if (xi < d.smin2[i]) { qv = d.smin2[i] - xi; L = d.penalty2; }
+                    WV(oV, i) += -L * qv;
+                    WS(oM, i, i, NX) += (L != 0.0) ? d.pen_xx2 : 0.0;
+                }
+            }
+        }
+    };
+    auto is_v = [](int i) { return ND == 2 && i >= DOF && i < 2 * DOF; };
+
     int kpi = d.n_kp - 1;
-    UNR for (int i = 0; i < NX; i++) x[i] = AT(X, (T - 1) * NX + i, b);
+    NOUNR for (int i = 0; i < NX; i++) WV(ox, i) = AT(X, (T - 1) * NX + i, b);
     {
         const bool iskp = (kpi >= 0 && d.kp_t[kpi] == T - 1);
-        sweep_stage_derivs<S>(d, a, b, iskp ? kpi : -1, x, P, p);
+        stage_to_ws(iskp ? kpi : -1, oP, op);
         if (iskp) kpi--;
     }
     for (int k = T - 2; k >= 0; k--) {
-        UNR for (int i = 0; i < NX; i++) x[i] = AT(X, k * NX + i, b);
-        UNR for (int i = 0; i < NU; i++) u[i] = AT(U, k * NU + i, b);
-        const double dts = TM ? u[NU - 1] : 0.0;
+        NOUNR for (int i = 0; i < NX; i++) WV(ox, i) = AT(X, k * NX + i, b);
+        const double* u = U + (size_t)k * NU * Bp + b;  // u_i = u[i Bp]
+        const double dts = TM ? u[(size_t)(NU - 1) * Bp] : 0.0;
         const double dt = TM ? dts * dts : d.dt;
         const double hdt2 = dt * dt / 2;
         // last column of B for time systems (PosOrnTimePlannerSys.cpp:161-162,176)
-        double bc[NX];
         if (TM) {
             if (ND == 1) {
-                UNR for (int i = 0; i < DOF; i++) bc[i] = 2 * dts * u[i];
+                NOUNR for (int i = 0; i < DOF; i++) WV(obc, i) = 2 * dts * u[(size_t)i * Bp];
             } else {
-                UNR for (int i = 0; i < DOF; i++) {
-                    double dqn = x[DOF + i] + dt * u[i];  // velocity AFTER the step
-                    bc[i] = 2 * dts * dqn + 2 * dts * dts * dts * u[i];
-                    bc[DOF + i] = 2 * dts * u[i];
+                NOUNR for (int i = 0; i < DOF; i++) {
+                    const double ui = u[(size_t)i * Bp];
+                    double dqn = WV(ox, DOF + i) + dt * ui;  // velocity AFTER the step
+                    WV(obc, i) = 2 * dts * dqn + 2 * dts * dts * dts * ui;
+                    WV(obc, DOF + i) = 2 * dts * ui;
                 }
             }
-            bc[NX - 1] = 2 * dts;
+            WV(obc, NX - 1) = 2 * dts;
         }
-        double lxx[NX][NX], lx[NX];
-        {
+        {   // l_xx, l_x of the stage go straight into the Qxx / Qx slots (Qxx = l_xx + A'PA below)
             const bool iskp = (kpi >= 0 && d.kp_t[kpi] == k);
-            sweep_stage_derivs<S>(d, a, b, iskp ? kpi : -1, x, lxx, lx);
+            stage_to_ws(iskp ? kpi : -1, oQxx, oQx);
             if (iskp) kpi--;
         }
         // BtP = B^T P (NU x NX), AtP = A^T P (NX x NX)
-        double BtP[NU][NX], AtP[NX][NX];
-        UNR for (int i = 0; i < DOF; i++)
-            UNR for (int j = 0; j < NX; j++)
-                BtP[i][j] = (ND == 1) ? dt * P[i][j] : hdt2 * P[i][j] + dt * P[DOF + i][j];
+        NOUNR for (int i = 0; i < DOF; i++)
+            NOUNR for (int j = 0; j < NX; j++)
+                WS(oBtP, i, j, NX) = (ND == 1) ? dt * WS(oP, i, j, NX) : hdt2 * WS(oP, i, j, NX) + dt * WS(oP, DOF + i, j, NX);
         if (TM) {
-            UNR for (int j = 0; j < NX; j++) {
+            NOUNR for (int j = 0; j < NX; j++) {
                 double s = 0;
-                UNR for (int l = 0; l < NX; l++) s += bc[l] * P[l][j];
-                BtP[NU - 1][j] = s;
+                NOUNR for (int l = 0; l < NX; l++) s += WV(obc, l) * WS(oP, l, j, NX);
+                WS(oBtP, NU - 1, j, NX) = s;
             }
         }
-        UNR for (int i = 0; i < NX; i++)
-            UNR for (int j = 0; j < NX; j++)
-                AtP[i][j] = (ND == 2 && i >= DOF && i < 2 * DOF) ? dt * P[i - DOF][j] + P[i][j] : P[i][j];
+        NOUNR for (int i = 0; i < NX; i++)
+            NOUNR for (int j = 0; j < NX; j++)
+                WS(oAtP, i, j, NX) = is_v(i) ? dt * WS(oP, i - DOF, j, NX) + WS(oP, i, j, NX) : WS(oP, i, j, NX);
         // Qux = BtP A ; Quu = R + BtP B ; Qxx = lxx + AtP A ; Qxu = AtP B ; Qu = R u + B^T p ; Qx = lx + A^T p
-        double Qux[NU][NX], Quu[NU][NU], Qxx[NX][NX], Qxu[NX][NU], Qu[NU], Qx[NX];
-        UNR for (int i = 0; i < NU; i++) {
-            UNR for (int j = 0; j < NX; j++)
-                Qux[i][j] = (ND == 2 && j >= DOF && j < 2 * DOF) ? BtP[i][j - DOF] * dt + BtP[i][j] : BtP[i][j];
-            UNR for (int j = 0; j < DOF; j++)
-                Quu[i][j] = (ND == 1) ? BtP[i][j] * dt : BtP[i][j] * hdt2 + BtP[i][DOF + j] * dt;
+        NOUNR for (int i = 0; i < NU; i++) {
+            NOUNR for (int j = 0; j < NX; j++)
+                WS(oQux, i, j, NX) = is_v(j) ? WS(oBtP, i, j - DOF, NX) * dt + WS(oBtP, i, j, NX) : WS(oBtP, i, j, NX);
+            NOUNR for (int j = 0; j < DOF; j++)
+                WS(oQuu, i, j, NU) = (ND == 1) ? WS(oBtP, i, j, NX) * dt : WS(oBtP, i, j, NX) * hdt2 + WS(oBtP, i, DOF + j, NX) * dt;
             if (TM) {
                 double s = 0;
-                UNR for (int l = 0; l < NX; l++) s += BtP[i][l] * bc[l];
-                Quu[i][NU - 1] = s;
+                NOUNR for (int l = 0; l < NX; l++) s += WS(oBtP, i, l, NX) * WV(obc, l);
+                WS(oQuu, i, NU - 1, NU) = s;
             }
-            Quu[i][i] = d.R_diag[i] + Quu[i][i];
+            WS(oQuu, i, i, NU) = d.R_diag[i] + WS(oQuu, i, i, NU);
         }
-        UNR for (int i = 0; i < NX; i++) {
-            UNR for (int j = 0; j < NX; j++) {
-                double v = (ND == 2 && j >= DOF && j < 2 * DOF) ? AtP[i][j - DOF] * dt + AtP[i][j] : AtP[i][j];
-                Qxx[i][j] = lxx[i][j] + v;
+        NOUNR for (int i = 0; i < NX; i++) {
+            NOUNR for (int j = 0; j < NX; j++) {
+                double v = is_v(j) ? WS(oAtP, i, j - DOF, NX) * dt + WS(oAtP, i, j, NX) : WS(oAtP, i, j, NX);
+                WS(oQxx, i, j, NX) = WS(oQxx, i, j, NX) + v;
             }
-            UNR for (int j = 0; j < DOF; j++)
-                Qxu[i][j] = (ND == 1) ? AtP[i][j] * dt : AtP[i][j] * hdt2 + AtP[i][DOF + j] * dt;
+            NOUNR for (int j = 0; j < DOF; j++)
+                WS(oQxu, i, j, NU) = (ND == 1) ? WS(oAtP, i, j, NX) * dt : WS(oAtP, i, j, NX) * hdt2 + WS(oAtP, i, DOF + j, NX) * dt;
             if (TM) {
                 double s = 0;
-                UNR for (int l = 0; l < NX; l++) s += AtP[i][l] * bc[l];
-                Qxu[i][NU - 1] = s;
+                NOUNR for (int l = 0; l < NX; l++) s += WS(oAtP, i, l, NX) * WV(obc, l);
+                WS(oQxu, i, NU - 1, NU) = s;
             }
         }
-        UNR for (int i = 0; i < DOF; i++) {
-            double v = (ND == 1) ? dt * p[i] : hdt2 * p[i] + dt * p[DOF + i];
-            Qu[i] = d.R_diag[i] * u[i] + v;
+        NOUNR for (int i = 0; i < DOF; i++) {
+            double v = (ND == 1) ? dt * WV(op, i) : hdt2 * WV(op, i) + dt * WV(op, DOF + i);
+            WV(oQu, i) = d.R_diag[i] * u[(size_t)i * Bp] + v;
         }
         if (TM) {
             double s = 0;
-            UNR for (int l = 0; l < NX; l++) s += bc[l] * p[l];
-            Qu[NU - 1] = d.R_diag[NU - 1] * u[NU - 1] + s;
+            NOUNR for (int l = 0; l < NX; l++) s += WV(obc, l) * WV(op, l);
+            WV(oQu, NU - 1) = d.R_diag[NU - 1] * u[(size_t)(NU - 1) * Bp] + s;
         }
-        UNR for (int i = 0; i < NX; i++) {
-            double v = (ND == 2 && i >= DOF && i < 2 * DOF) ? dt * p[i - DOF] + p[i] : p[i];
-            Qx[i] = lx[i] + v;
+        NOUNR for (int i = 0; i < NX; i++) {
+            double v = is_v(i) ? dt * WV(op, i - DOF) + WV(op, i) : WV(op, i);
+            WV(oQx, i) = WV(oQx, i) + v;
         }
         if (AL) {  // AL-ILQR.cpp:110-134: c_u' I c_x etc., lambda + I c
             const int ns = NX + NU;
@@ -224,67 +268,109 @@ __global__ __launch_bounds__(64) void k_backward(Bufs a) {
                 const double* Ar = a.conA + ((size_t)(a.per_step ? k : 0) * a.m + r) * ns;
                 const double Ik = AT(a.Is, k * a.m + r, b);
                 const double lam = AT(a.lambda, k * a.m + r, b);
-                const double g = con_g<S>(a, k, r, x, u);
+                double g = 0;  // con_g (ilqr_step.hpp): A [x;u] - b, same order
+                NOUNR for (int i = 0; i < NX; i++) g += Ar[i] * WV(ox, i);
+                NOUNR for (int i = 0; i < NU; i++) g += Ar[NX + i] * u[(size_t)i * Bp];
+                g = g - a.conb[(size_t)(a.per_step ? k : 0) * a.m + r];
                 const double wv = lam + Ik * g;
-                UNR for (int i = 0; i < NU; i++) {
+                NOUNR for (int i = 0; i < NU; i++) {
                     const double au = Ar[NX + i];
-                    UNR for (int j = 0; j < NX; j++) Qux[i][j] += au * Ik * Ar[j];
-                    UNR for (int j = 0; j < NU; j++) Quu[i][j] += au * Ik * Ar[NX + j];
-                    Qu[i] += au * wv;
+                    NOUNR for (int j = 0; j < NX; j++) WS(oQux, i, j, NX) += au * Ik * Ar[j];
+                    NOUNR for (int j = 0; j < NU; j++) WS(oQuu, i, j, NU) += au * Ik * Ar[NX + j];
+                    WV(oQu, i) += au * wv;
                 }
-                UNR for (int i = 0; i < NX; i++) {
+                NOUNR for (int i = 0; i < NX; i++) {
                     const double ax = Ar[i];
-                    UNR for (int j = 0; j < NX; j++) Qxx[i][j] += ax * Ik * Ar[j];
-                    UNR for (int j = 0; j < NU; j++) Qxu[i][j] += ax * Ik * Ar[NX + j];
-                    Qx[i] += ax * wv;
+                    NOUNR for (int j = 0; j < NX; j++) WS(oQxx, i, j, NX) += ax * Ik * Ar[j];
+                    NOUNR for (int j = 0; j < NU; j++) WS(oQxu, i, j, NU) += ax * Ik * Ar[NX + j];
+                    WV(oQx, i) += ax * wv;
                 }
             }
         }
-        // Quu_inv = -(Quu + reg I)^-1 ; K = Quu_inv Qux ; d = Quu_inv Qu
-        double Mr[NU][NU], Qi[NU][NU];
-        UNR for (int i = 0; i < NU; i++)
-            UNR for (int j = 0; j < NU; j++) Mr[i][j] = Quu[i][j] + ((i == j) ? d.reg : 0.0);
-        inverse_lu<NU>(Mr, Qi);
-        double Kk[NU][NX], dk[NU];
-        UNR for (int i = 0; i < NU; i++) {
-            UNR for (int j = 0; j < NX; j++) {
+        // Quu_inv = -(Quu + reg I)^-1 ; K = Quu_inv Qux ; d = Quu_inv Qu.  Inverse: Eigen's MatrixXd::inverse() = PartialPivLU + solve against
+        // the identity (the algorithm of inverse_lu in ilqr_step.hpp, on the workspace)
+        NOUNR for (int i = 0; i < NU; i++)
+            NOUNR for (int j = 0; j < NU; j++) WS(oMr, i, j, NU) = WS(oQuu, i, j, NU) + ((i == j) ? d.reg : 0.0);
+        {
+            unsigned long long piv = 0;  // row permutation, 4 bits per row
+            NOUNR for (int i = 0; i < NU; i++) piv |= (unsigned long long)i << (4 * i);
+            NOUNR for (int kk = 0; kk < NU; kk++) {
+                double best = fabs(WS(oMr, kk, kk, NU));
+                int r = kk;
+                NOUNR for (int i = kk + 1; i < NU; i++) {
+                    const double v = fabs(WS(oMr, i, kk, NU));
+                    if (v > best) { best = v; r = i; }
+                }
+                if (r != kk) {
+                    NOUNR for (int j = 0; j < NU; j++) {
+                        const double t0 = WS(oMr, kk, j, NU), t1 = WS(oMr, r, j, NU);
+                        WS(oMr, kk, j, NU) = t1;
+                        WS(oMr, r, j, NU) = t0;
+                    }
+                    const unsigned long long p0 = (piv >> (4 * kk)) & 15ull, p1 = (piv >> (4 * r)) & 15ull;
+                    piv = (piv & ~((15ull << (4 * kk)) | (15ull << (4 * r)))) | (p1 << (4 * kk)) | (p0 << (4 * r));
+                }
+                const double pv = WS(oMr, kk, kk, NU);
+                NOUNR for (int i = kk + 1; i < NU; i++) {
+                    WS(oMr, i, kk, NU) /= pv;
+                    const double f = WS(oMr, i, kk, NU);
+                    NOUNR for (int j = kk + 1; j < NU; j++) WS(oMr, i, j, NU) -= f * WS(oMr, kk, j, NU);
+                }
+            }
+            NOUNR for (int c = 0; c < NU; c++) {
+                NOUNR for (int i = 0; i < NU; i++) {
+                    double s = ((int)((piv >> (4 * i)) & 15ull) == c) ? 1.0 : 0.0;
+                    NOUNR for (int j = 0; j < i; j++) s -= WS(oMr, i, j, NU) * WS(oQi, j, c, NU);
+                    WS(oQi, i, c, NU) = s;
+                }
+                NOUNR for (int i = NU - 1; i >= 0; i--) {
+                    double s = WS(oQi, i, c, NU);
+                    NOUNR for (int j = i + 1; j < NU; j++) s -= WS(oMr, i, j, NU) * WS(oQi, j, c, NU);
+                    WS(oQi, i, c, NU) = s / WS(oMr, i, i, NU);
+                }
+            }
+        }
+        double* const Krec = KD_REC(a.KD, Bp, NU * kd_rowp(NX), k, b);
+        NOUNR for (int i = 0; i < NU; i++) {
+            NOUNR for (int j = 0; j < NX; j++) {
                 double s = 0;
-                UNR for (int l = 0; l < NU; l++) s += (-1 * Qi[i][l]) * Qux[l][j];
-                Kk[i][j] = s;
-                KD_REC(a.KD, Bp, NU * kd_rowp(NX), k, b)[i * kd_rowp(NX) + j] = s;
+                NOUNR for (int l = 0; l < NU; l++) s += (-1 * WS(oQi, i, l, NU)) * WS(oQux, l, j, NX);
+                WS(oK, i, j, NX) = s;
+                Krec[i * kd_rowp(NX) + j] = s;
             }
             double s = 0;
-            UNR for (int l = 0; l < NU; l++) s += (-1 * Qi[i][l]) * Qu[l];
-            dk[i] = s;
-            KD_REC(a.KD, Bp, NU * kd_rowp(NX), k, b)[i * kd_rowp(NX) + NX] = s;
+            NOUNR for (int l = 0; l < NU; l++) s += (-1 * WS(oQi, i, l, NU)) * WV(oQu, l);
+            WV(odk, i) = s;
+            Krec[i * kd_rowp(NX) + NX] = s;
         }
         // P = Qxx + K'QuuK + K'Qux + QxuK ; p = Qx + K'Quu d + K'Qu + Qxu d   (un-regularised Quu)
-        double KtQuu[NX][NU];
-        UNR for (int i = 0; i < NX; i++)
-            UNR for (int j = 0; j < NU; j++) {
+        NOUNR for (int i = 0; i < NX; i++)
+            NOUNR for (int j = 0; j < NU; j++) {
                 double s = 0;
-                UNR for (int l = 0; l < NU; l++) s += Kk[l][i] * Quu[l][j];
-                KtQuu[i][j] = s;
+                NOUNR for (int l = 0; l < NU; l++) s += WS(oK, l, i, NX) * WS(oQuu, l, j, NU);
+                WS(oKtQ, i, j, NU) = s;
             }
-        UNR for (int i = 0; i < NX; i++) {
-            UNR for (int j = 0; j < NX; j++) {
+        NOUNR for (int i = 0; i < NX; i++) {
+            NOUNR for (int j = 0; j < NX; j++) {
                 double t1 = 0, t2 = 0, t3 = 0;
-                UNR for (int l = 0; l < NU; l++) {
-                    t1 += KtQuu[i][l] * Kk[l][j];
-                    t2 += Kk[l][i] * Qux[l][j];
-                    t3 += Qxu[i][l] * Kk[l][j];
+                NOUNR for (int l = 0; l < NU; l++) {
+                    t1 += WS(oKtQ, i, l, NU) * WS(oK, l, j, NX);
+                    t2 += WS(oK, l, i, NX) * WS(oQux, l, j, NX);
+                    t3 += WS(oQxu, i, l, NU) * WS(oK, l, j, NX);
                 }
-                P[i][j] = ((Qxx[i][j] + t1) + t2) + t3;
+                WS(oP, i, j, NX) = ((WS(oQxx, i, j, NX) + t1) + t2) + t3;
             }
             double v1 = 0, v2 = 0, v3 = 0;
-            UNR for (int l = 0; l < NU; l++) {
-                v1 += KtQuu[i][l] * dk[l];
-                v2 += Kk[l][i] * Qu[l];
-                v3 += Qxu[i][l] * dk[l];
+            NOUNR for (int l = 0; l < NU; l++) {
+                v1 += WS(oKtQ, i, l, NU) * WV(odk, l);
+                v2 += WS(oK, l, i, NX) * WV(oQu, l);
+                v3 += WS(oQxu, i, l, NU) * WV(odk, l);
             }
-            p[i] = ((Qx[i] + v1) + v2) + v3;
+            WV(op, i) = ((WV(oQx, i) + v1) + v2) + v3;
         }
     }
+#undef WS
+#undef WV
 }
 
 // Forward pass with step-halving line search (ILQRRecursive.cpp:101-176).  Each trial re-rolls the whole horizon

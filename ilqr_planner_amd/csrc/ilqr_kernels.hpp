@@ -32,6 +32,7 @@ struct Bufs {
     double* kpdev;  // [n_kp][NX+NU][Bp] deviation (dx, du) of that rollout at the keypoint steps
     double* kpx;    // [n_kp][16][NX+NU][Bp] state | control of every alpha's rollout at the keypoint steps (k_forward_mfma -> k_select_x)
     double* dunA;   // [16][Bp] sum_k ||du_k|| of every alpha's rollout
+    double* ws;     // [backward_ws_entries][Bp] matrices of a step of the generic sweep (k_backward), allocated at its first use
     double* cost_trace;   // [nb_iter][Bp] or null
     double* alpha_trace;  // [nb_iter][Bp] or null
     // augmented Lagrangian (shared constraint rows, per-instance multipliers)
@@ -75,6 +76,7 @@ bool backward_si_supported(int kind, int nd, bool al, int m, int per_step, bool 
 void launch_solver_v2(int kind, int nd, int which, bool al, const Bufs& a, int B, int T, hipStream_t st, const FwdArgs& f);
 void launch_backward_si_coop(bool al, bool fused, const Bufs& a, int B, hipStream_t st, const SweepArgs& sw);
 bool backward_mfma_supported(int kind, int nd, bool al, int m);
+int backward_ws_entries(int kind, int nd);  // doubles per instance of k_backward's workspace
 void launch_backward_mfma(int kind, int nd, bool al, const Bufs& a, int B, hipStream_t st);  // needs KER_KP_DERIVS first
 bool forward_lin_supported(int kind, int nd, int n_alpha);
 void launch_forward_mfma(int kind, int nd, const Bufs& a, int B, hipStream_t st, const FwdArgs& f);  // time systems: all step sizes of an instance as one matrix-core product per step (ilqr_kernels_fwdm.hip)
