@@ -766,6 +766,17 @@ Mat System::cost_xx(const Vec& xk, const Vec&, int k) {  // :286-308
     return H;
 }
 
+bool System::builtin() const {
+    if (!builtinType()) return false;
+    for (auto& k : keypoints) {
+        const std::type_info& t = typeid(*k);
+        if (!(t == typeid(PosOrnKeypoint) || t == typeid(PosOrnKeypointDistFunct) || t == typeid(AngularKeypoint) || t == typeid(AngularTimeKeypoint) ||
+              t == typeid(SpacetimeKeypoint)))
+            return false;
+    }
+    return true;
+}
+
 void System::lower(ilqr_problem_desc* d) const {
     ilqr_desc_defaults(d);
     if (!r->lowerChain(d)) {
@@ -943,6 +954,13 @@ Mat SequentialSystem::getQMatrix(bool sparse) {
 }
 // Device form: dynamics, chain and limits of the first sub-system; every keypoint keeps the frame and the control penalty of
 // its own sub-system; the limit terms count once per sub-system (SequentialSystem.cpp:144-168 sums cost, cost_x, cost_xx).
+bool SequentialSystem::builtinType() const {
+    if (typeid(*this) != typeid(SequentialSystem)) return false;
+    for (auto& sy : systems_)
+        if (!sy->builtin()) return false;
+    return true;
+}
+
 void SequentialSystem::lower(ilqr_problem_desc* d) const {
     std::vector<ilqr_problem_desc> subs(systems_.size());
     for (size_t i = 0; i < systems_.size(); i++) systems_[i]->lower(&subs[i]);
@@ -1368,6 +1386,8 @@ static std::string fmt(double v) {
 static BatchResult run_batch(sys::System& s, const BatchInputs& in, int nb_iter, bool gains, const ilqr_problem_desc* override_desc,
                              const std::function<void(ilqr_problem*)>& pre_solve, const std::function<void(ilqr_problem*)>& solve,
                              const std::function<void(ilqr_problem*)>& post_solve) {
+    if (!s.builtin())
+        throw std::runtime_error("[ilqr_hip] a user-defined System / Keypoint subclass has no device lowering: only ILQRRecursive::solve runs it (over its virtuals)");
     ilqr_problem_desc d;
     if (override_desc) d = *override_desc;
     else s.lower(&d);
@@ -1524,6 +1544,7 @@ BatchResult ILQRRecursive::solveBatch(const BatchInputs& in, int nb_iter, bool l
 
 std::tuple<std::vector<Vec>, std::vector<Vec>, std::vector<Vec>, std::vector<Mat>, std::vector<Vec>, double> ILQRRecursive::solve(
     const std::vector<Vec>& U0, int nb_iter, bool line_search, bool early_stop, CallBackMessage* cb) {  // ILQRRecursive.cpp:21-181
+    if (!s->builtin()) return solve_over_virtuals(*s, U0, nb_iter, line_search, early_stop, cb);  // user-defined System / Keypoint
     BatchInputs in;
     in.B = 1;
     in.U0 = flatten(U0, s->getHorizon(), s->getNbCtrlVar());

@@ -8,11 +8,13 @@
 //   primitives, Sd, CallBackMessage                   include/ilqr_planner/utils/*.h
 // No Eigen (absent from this image): Vec/Mat are plain row-major containers.  These classes hold state and LOWER it to
 // the POD descriptor of include/ilqr_hip.h; every solve and every kinematics evaluation runs on the GPU through that C
-// ABI -- there is no host solver.  The single-point System API (forwardPass, cost*, getFxJac, fpBatch ...) is host glue over
+// ABI -- there is no host solver for them (user-defined System / Keypoint subclasses, which have no descriptor, run
+// solver::ILQRRecursive over their own virtuals: ilqr_host_loop.cpp).  The single-point System API (forwardPass, cost*, getFxJac, fpBatch ...) is host glue over
 // the simulator for users who call it directly; the solvers never use it.  NOT mirrored: BatchILQR (no PSI), LQT -- see DESIGN.md.
 #pragma once
 
 #include <memory>
+#include <typeinfo>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -293,6 +295,7 @@ public:
     const std::vector<std::shared_ptr<Keypoint>>& getKeypoints() const { return keypoints; }
     // Lowering to the C ABI's POD descriptor.  Throws for systems the device cannot run.
     virtual void lower(ilqr_problem_desc* d) const;
+    virtual bool builtinType() const { return false; }  // overridden by the classes of this header: typeid(*this) == typeid(<that class>)
     // per-instance pieces for B = 1: q0, dq0 captured by localInit
     Vec q0() const { return q0_; }
     Vec dq0() const { return dq0_; }
@@ -300,6 +303,10 @@ public:
     // joint-space systems of robots with fewer than 7 joints are padded to the device's 7 (zero precision, zero limit weight, u = 0):
     // number of joints the user sees, 0 = no padding
     virtual int paddedFromDof() const { return 0; }
+    // true for the system classes of this header exactly as declared here (with built-in keypoints): the shapes the device descriptor
+    // describes.  A user-defined subclass -- also one derived from a built-in class -- answers false and is solved over its virtuals by
+    // ILQRRecursive::solve (ilqr_host_loop.cpp); the choice is made on the type, never on whether a device call succeeded.
+    bool builtin() const;
     const Vec& Rt() const { return Rdiag; }
     int kind() const { return kind_; }
 
@@ -322,6 +329,7 @@ protected:
 
 class PosOrnPlannerSys : public System {  // PosOrnPlannerSys.h
 public:
+    bool builtinType() const override { return typeid(*this) == typeid(PosOrnPlannerSys); }
     PosOrnPlannerSys(const std::shared_ptr<sim::SimulationInterface>& r, const std::vector<std::shared_ptr<Keypoint>>& keypoints, const Vec& RtDiag,
                      const Vec& qMax, const Vec& qMin, const Vec& dqMax, const Vec& dqMin, int horizon, int nb_deriv, double dt);
     PosOrnPlannerSys(const std::shared_ptr<sim::SimulationInterface>& r, const std::vector<std::shared_ptr<Keypoint>>& keypoints, const Vec& RtDiag,
@@ -342,6 +350,7 @@ protected:
 // kernels are built for (the reference's 2nd-order variant is dimensionally inconsistent).
 class JointSpacePlannerSys : public System {
 public:
+    bool builtinType() const override { return typeid(*this) == typeid(JointSpacePlannerSys); }
     JointSpacePlannerSys(const std::shared_ptr<sim::SimulationInterface>& r, const std::vector<std::shared_ptr<Keypoint>>& keypoints, const Vec& RtDiag,
                          const Vec& qMax, const Vec& qMin, const Vec& dqMax, const Vec& dqMin, int horizon, int nb_deriv, double dt);
     JointSpacePlannerSys(const std::shared_ptr<sim::SimulationInterface>& r, const std::vector<std::shared_ptr<Keypoint>>& keypoints, const Vec& RtDiag,
@@ -363,6 +372,7 @@ protected:
 // JointSpacePlannerSys with a time state and dt = u_last^2 (JointSpaceTimePlannerSys.h / .cpp:50-160); nb_deriv = 1, 7 joints on the device
 class JointSpaceTimePlannerSys : public System {
 public:
+    bool builtinType() const override { return typeid(*this) == typeid(JointSpaceTimePlannerSys); }
     JointSpaceTimePlannerSys(const std::shared_ptr<sim::SimulationInterface>& r, const std::vector<std::shared_ptr<Keypoint>>& keypoints, const Vec& RtDiag,
                              const Vec& qMax, const Vec& qMin, const Vec& dqMax, const Vec& dqMin, int horizon, int nb_deriv);
     JointSpaceTimePlannerSys(const std::shared_ptr<sim::SimulationInterface>& r, const std::vector<std::shared_ptr<Keypoint>>& keypoints, const Vec& RtDiag,
@@ -383,6 +393,7 @@ protected:
 
 class PosOrnTimePlannerSys : public System {  // PosOrnTimePlannerSys.h
 public:
+    bool builtinType() const override { return typeid(*this) == typeid(PosOrnTimePlannerSys); }
     PosOrnTimePlannerSys(const std::shared_ptr<sim::SimulationInterface>& r, const std::vector<std::shared_ptr<Keypoint>>& keypoints, const Vec& RtDiag,
                          const Vec& qMax, const Vec& qMin, const Vec& dqMax, const Vec& dqMin, int horizon, int nb_deriv);
     PosOrnTimePlannerSys(const std::shared_ptr<sim::SimulationInterface>& r, const std::vector<std::shared_ptr<Keypoint>>& keypoints, const Vec& RtDiag,
@@ -402,6 +413,7 @@ protected:
 // all (each in its own sub-system's frame, with that sub-system's control penalty), limit terms once per sub-system.
 class SequentialSystem : public System {
 public:
+    bool builtinType() const override;  // ... and every sub-system is
     SequentialSystem(const std::shared_ptr<sim::SimulationInterface>& r, const std::vector<std::shared_ptr<System>>& systems, const Vec& RtDiag,
                      int horizon, int nb_deriv);
     Vec getState() override { return systems_.at(0)->getState(); }
@@ -452,6 +464,10 @@ struct Constraint {  // AL-ILQR.h:20-23
     Mat A;
     Vec b;
 };
+
+// ILQRRecursive over the virtual interface of a user-defined system (ilqr_host_loop.cpp)
+std::tuple<std::vector<Vec>, std::vector<Vec>, std::vector<Vec>, std::vector<Mat>, std::vector<Vec>, double> solve_over_virtuals(
+    sys::System& s, const std::vector<Vec>& U0, int nb_iter, bool line_search, bool early_stop, CallBackMessage* cb);
 
 class ILQRRecursive {  // ILQRRecursive.h:21-42
 public:

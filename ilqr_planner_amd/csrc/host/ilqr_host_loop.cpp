@@ -1,0 +1,213 @@
+// ilqr_host_loop.cpp -- ILQRRecursive over the virtual System interface, for USER-DEFINED System / Keypoint subclasses only.
+//
+// SURVEY.md section 8(b), last bullet: the reference's solver is written against the virtuals of sys::System (forwardPass, cost, cost_x,
+// cost_xx, cost_F*; ILQRRecursive.cpp:21-181), so a C++ user may hand it a System of their own.  Such a system has no lowering to the
+// device descriptor (include/ilqr_hip.h describes the built-in system shapes), so the mirror runs it with this loop: the same algorithm
+// stated over the mirror's virtuals, on the mirror's own Vec / Mat.
+//
+// What this is NOT: a fallback for the device path.  Every built-in system shape (PosOrn / PosOrnTime / JointSpace / JointSpaceTime
+// planner systems, sequences of them, the built-in keypoints) is lowered and solved on the GPU, and fails loudly when that is not possible;
+// ILQRRecursive::solve chooses by the TYPE of the system (System::builtin()), never by whether a device call succeeded.  Nothing under
+// oracle/ is used here or anywhere else in the product.
+#include <cmath>
+#include <iostream>
+#include <sstream>
+#include <stdexcept>
+
+#include "ilqr_host.hpp"
+
+namespace ilqr_planner {
+namespace solver {
+namespace {
+
+Mat mul(const Mat& a, const Mat& b) {
+    Mat o(a.rows, b.cols);
+    for (int i = 0; i < a.rows; i++)
+        for (int j = 0; j < b.cols; j++) {
+            double s = 0;
+            for (int l = 0; l < a.cols; l++) s += a(i, l) * b(l, j);
+            o(i, j) = s;
+        }
+    return o;
+}
+Mat tmul(const Mat& a, const Mat& b) {  // a^T b
+    Mat o(a.cols, b.cols);
+    for (int i = 0; i < a.cols; i++)
+        for (int j = 0; j < b.cols; j++) {
+            double s = 0;
+            for (int l = 0; l < a.rows; l++) s += a(l, i) * b(l, j);
+            o(i, j) = s;
+        }
+    return o;
+}
+Vec mulv(const Mat& a, const Vec& v) {
+    Vec o(a.rows, 0.0);
+    for (int i = 0; i < a.rows; i++) {
+        double s = 0;
+        for (int l = 0; l < a.cols; l++) s += a(i, l) * v[l];
+        o[i] = s;
+    }
+    return o;
+}
+Vec tmulv(const Mat& a, const Vec& v) {  // a^T v
+    Vec o(a.cols, 0.0);
+    for (int i = 0; i < a.cols; i++) {
+        double s = 0;
+        for (int l = 0; l < a.rows; l++) s += a(l, i) * v[l];
+        o[i] = s;
+    }
+    return o;
+}
+Mat add(const Mat& a, const Mat& b) {
+    Mat o = a;
+    for (size_t i = 0; i < o.d.size(); i++) o.d[i] += b.d[i];
+    return o;
+}
+Vec addv(const Vec& a, const Vec& b) {
+    Vec o = a;
+    for (size_t i = 0; i < o.size(); i++) o[i] += b[i];
+    return o;
+}
+// inverse by LU with partial pivoting, solved against the identity (what MatrixXd::inverse() does for these sizes)
+Mat inverse(Mat m) {
+    const int n = m.rows;
+    if (m.cols != n) throw std::runtime_error("[ILQRRecursive] Quu is not square");
+    std::vector<int> piv(n);
+    for (int i = 0; i < n; i++) piv[i] = i;
+    for (int k = 0; k < n; k++) {
+        int r = k;
+        double best = std::fabs(m(k, k));
+        for (int i = k + 1; i < n; i++)
+            if (std::fabs(m(i, k)) > best) { best = std::fabs(m(i, k)); r = i; }
+        if (r != k) {
+            for (int j = 0; j < n; j++) std::swap(m(k, j), m(r, j));
+            std::swap(piv[k], piv[r]);
+        }
+        const double pv = m(k, k);
+        for (int i = k + 1; i < n; i++) {
+            m(i, k) /= pv;
+            const double f = m(i, k);
+            for (int j = k + 1; j < n; j++) m(i, j) -= f * m(k, j);
+        }
+    }
+    Mat inv(n, n);
+    for (int c = 0; c < n; c++) {
+        for (int i = 0; i < n; i++) {
+            double s = (piv[i] == c) ? 1.0 : 0.0;
+            for (int j = 0; j < i; j++) s -= m(i, j) * inv(j, c);
+            inv(i, c) = s;
+        }
+        for (int i = n - 1; i >= 0; i--) {
+            double s = inv(i, c);
+            for (int j = i + 1; j < n; j++) s -= m(i, j) * inv(j, c);
+            inv(i, c) = s / m(i, i);
+        }
+    }
+    return inv;
+}
+std::string num(double v) {
+    std::ostringstream o;
+    o << v;
+    return o.str();
+}
+
+}  // namespace
+
+// ILQRRecursive::solve (ILQRRecursive.cpp:21-181) over the virtual interface of `s`.
+std::tuple<std::vector<Vec>, std::vector<Vec>, std::vector<Vec>, std::vector<Mat>, std::vector<Vec>, double> solve_over_virtuals(
+    sys::System& s, const std::vector<Vec>& U0, int nb_iter, bool line_search, bool early_stop, CallBackMessage* cb) {
+    const int T = s.getHorizon(), nu = s.getNbCtrlVar();
+    if ((int)U0.size() != T - 1) throw std::runtime_error("[solver] U0 must hold horizon-1 control vectors");
+    for (auto& u : U0)
+        if ((int)u.size() != nu) throw std::runtime_error("[solver] each U0 entry must have nb_ctrl_var entries");
+    const Vec zero_u(nu, 0.0);
+    std::vector<Vec> X(T), fX(T), U = U0, nX(T), nfX(T), nU(T - 1), ds(T - 1);
+    std::vector<Mat> As(T - 1), Bs(T - 1), Ks(T - 1);
+
+    // initial rollout (:41-56)
+    s.reset();
+    X[0] = s.getState();
+    fX[0] = std::get<0>(s.getFxJac());
+    double cost0 = 0;
+    for (int k = 0; k < T - 1; k++) {
+        cost0 += s.cost(X[k], U[k], k)[0];
+        auto st = s.forwardPass(X[k], U[k], k);
+        X[k + 1] = std::get<0>(st);
+        fX[k + 1] = std::get<1>(st);
+        As[k] = std::get<2>(st);
+        Bs[k] = std::get<3>(st);
+    }
+    cost0 += s.cost_F(X[T - 1])[0];
+
+    double alpha = 1;
+    int it_done = 0;
+    for (int it = 0; it < nb_iter; it++) {
+        // backward pass (:68-97)
+        Mat P = s.cost_F_xx(X[T - 1]);
+        Vec p = s.cost_F_x(X[T - 1]);
+        for (int k = T - 2; k >= 0; k--) {
+            const Mat &A = As[k], &B = Bs[k];
+            const Mat BtP = tmul(B, P), AtP = tmul(A, P);
+            const Mat Qux = add(s.cost_ux(X[k], U[k], k), mul(BtP, A));
+            const Mat Quu = add(s.cost_uu(X[k], U[k], k), mul(BtP, B));
+            const Mat Qxx = add(s.cost_xx(X[k], U[k], k), mul(AtP, A));
+            const Mat Qxu = add(s.cost_xu(X[k], U[k], k), mul(AtP, B));
+            const Vec Qu = addv(s.cost_u(X[k], U[k], k), tmulv(B, p));
+            const Vec Qx = addv(s.cost_x(X[k], U[k], k), tmulv(A, p));
+            Mat Qr = Quu;
+            for (int i = 0; i < nu; i++) Qr(i, i) += 1e-6;  // the regularisation enters the inverse only (:89)
+            Mat Qi = inverse(Qr);
+            for (auto& v : Qi.d) v = -1 * v;
+            Ks[k] = mul(Qi, Qux);
+            ds[k] = mulv(Qi, Qu);
+            const Mat KtQuu = tmul(Ks[k], Quu);
+            const Mat t1 = mul(KtQuu, Ks[k]), t2 = tmul(Ks[k], Qux), t3 = mul(Qxu, Ks[k]);
+            for (size_t i = 0; i < P.d.size(); i++) P.d[i] = ((Qxx.d[i] + t1.d[i]) + t2.d[i]) + t3.d[i];
+            const Vec v1 = mulv(KtQuu, ds[k]), v2 = tmulv(Ks[k], Qu), v3 = mulv(Qxu, ds[k]);
+            for (size_t i = 0; i < p.size(); i++) p[i] = ((Qx[i] + v1[i]) + v2[i]) + v3[i];
+        }
+        // forward pass with the step-halving line search (:101-155): the last trial is accepted whatever its cost
+        alpha = 2;
+        double newCost = 0, dun = 0;
+        do {
+            alpha /= 2.0;
+            s.reset();
+            nX[0] = s.getState();
+            nfX[0] = std::get<0>(s.getFxJac());
+            dun = 0;
+            newCost = 0;
+            for (int k = 0; k < T - 1; k++) {
+                Vec dx(nX[k].size());
+                for (size_t i = 0; i < dx.size(); i++) dx[i] = nX[k][i] - X[k][i];
+                Vec du = mulv(Ks[k], dx);
+                double n2 = 0;
+                for (int i = 0; i < nu; i++) { du[i] += alpha * ds[k][i]; n2 += du[i] * du[i]; }
+                dun += std::sqrt(n2);
+                nU[k] = addv(U[k], du);
+                newCost += s.cost(nX[k], nU[k], k)[0];
+                auto st = s.forwardPass(nX[k], nU[k], k);
+                nX[k + 1] = std::get<0>(st);
+                nfX[k + 1] = std::get<1>(st);
+                As[k] = std::get<2>(st);
+                Bs[k] = std::get<3>(st);
+            }
+            newCost += s.cost_F(nX[T - 1])[0];
+        } while (((newCost >= cost0) || std::isnan(newCost)) && alpha > 1e-3 && line_search);
+        cost0 = newCost;
+        X = nX; fX = nfX; U = nU;
+        it_done = it + 1;
+        const std::string msg = "Iteration " + std::to_string(it + 1) + ", Cost: " + num(cost0) + ", alpha= " + num(alpha);
+        if (cb) cb->notify(msg);
+        else std::cout << msg << std::endl;
+        if (early_stop && alpha * std::sqrt(dun) < 1e-3 && cost0 < 1e-3) break;  // (:174)
+    }
+    s.reset();
+    std::vector<Vec> dso = ds;
+    for (auto& v : dso)
+        for (auto& e : v) e *= (it_done > 0 ? alpha : 1.0);  // the returned feed-forward terms are scaled by the accepted alpha (:128,144,162)
+    if (it_done == 0) { Ks.clear(); dso.clear(); }
+    return std::make_tuple(X, fX, U, Ks, dso, cost0);
+}
+
+}  // namespace solver
+}  // namespace ilqr_planner

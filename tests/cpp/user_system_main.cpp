@@ -1,0 +1,127 @@
+// A user-defined sys::System (a planar point mass: double integrator, quadratic terminal cost) solved by solver::ILQRRecursive over its
+// virtuals -- SURVEY section 8(b): "user-defined System / Keypoint subclasses run the CPU loop".  Checked without any reference to the
+// solver's internals: the returned trajectory is the rollout of the returned controls, the cost is the cost of that trajectory, and the
+// controls are a stationary point of the total cost (finite differences over every control entry).  Exit code 0 = all checks passed.
+#include <cmath>
+#include <cstdio>
+#include <stdexcept>
+
+#include "../../ilqr_planner_amd/csrc/host/ilqr_host.hpp"
+
+using namespace ilqr_planner;
+
+struct PointSys : sys::System {
+    double dt;
+    Vec x, xt, qdiag;
+    PointSys(int T, double dt_) : sys::System(nullptr, {}, Vec{1e-2, 1e-2}, T, 2, {}), dt(dt_) {
+        nb_state_var_ = 4; nb_ctrl_var_ = 2; nb_target_var_ = 4; nb_Q_var_ = 4;
+        x0_ = Vec{0.2, -0.1, 0.0, 0.3};
+        xt = Vec{1.0, 0.5, 0.0, 0.0};
+        qdiag = Vec{10, 10, 1, 1};
+        x = x0_;
+    }
+    Vec getState() override { return x; }
+    void reset() override { x = x0_; }
+    std::tuple<Vec, Mat> getFxJac() override { return std::make_tuple(x, Mat::Identity(4)); }
+    StepOut forwardPass(const Vec&, const Vec& u, int) override {  // advances the "simulator" (this object), as the reference's systems do
+        Mat A = Mat::Identity(4), B(4, 2);
+        A(0, 2) = dt; A(1, 3) = dt;
+        B(0, 0) = dt * dt / 2; B(1, 1) = dt * dt / 2; B(2, 0) = dt; B(3, 1) = dt;
+        Vec xn(4);
+        xn[0] = x[0] + dt * x[2] + dt * dt / 2 * u[0];
+        xn[1] = x[1] + dt * x[3] + dt * dt / 2 * u[1];
+        xn[2] = x[2] + dt * u[0];
+        xn[3] = x[3] + dt * u[1];
+        x = xn;
+        return std::make_tuple(x, x, A, B, Mat::Identity(4));
+    }
+    // the reference's convention: cost = e'Qe + u'Ru, derivatives WITHOUT the factor 2 (cost_x = -J'Qe, cost_xx = J'QJ, cost_u = Ru)
+    Vec cost(const Vec& xk, const Vec& uk, int k) override {
+        double c = 0;
+        if (k == horizon_ - 1)
+            for (int i = 0; i < 4; i++) c += qdiag[i] * (xt[i] - xk[i]) * (xt[i] - xk[i]);
+        for (int i = 0; i < 2; i++) c += Rdiag[i] * uk[i] * uk[i];
+        return Vec(1, c);
+    }
+    Vec cost_x(const Vec& xk, const Vec&, int k) override {
+        Vec g(4, 0.0);
+        if (k == horizon_ - 1)
+            for (int i = 0; i < 4; i++) g[i] = -qdiag[i] * (xt[i] - xk[i]);
+        return g;
+    }
+    Mat cost_xx(const Vec&, const Vec&, int k) override {
+        Mat H(4, 4);
+        if (k == horizon_ - 1)
+            for (int i = 0; i < 4; i++) H(i, i) = qdiag[i];
+        return H;
+    }
+    double total(const std::vector<Vec>& U) {  // independent of the solver: plain rollout
+        reset();
+        double c = 0;
+        for (int k = 0; k < horizon_ - 1; k++) {
+            c += cost(x, U[k], k)[0];
+            forwardPass(x, U[k], k);
+        }
+        c += cost(x, Vec(2, 0.0), horizon_ - 1)[0];
+        return c;
+    }
+};
+
+struct Collect : CallBackMessage {
+    int n = 0;
+    void notify(const std::string&) override { n++; }
+};
+
+#define CHECK(cond)                                                    \
+    do {                                                               \
+        if (!(cond)) { std::printf("FAILED: %s (line %d)\n", #cond, __LINE__); return 1; } \
+    } while (0)
+
+int main() {
+    const int T = 30;
+    auto s = std::make_shared<PointSys>(T, 0.1);
+    CHECK(!s->builtin());
+    std::vector<Vec> U0(T - 1, Vec{0.1, -0.2});
+    const double c_init = s->total(U0);
+    solver::ILQRRecursive solver_(s);
+    Collect cb;
+    auto out = solver_.solve(U0, 3, true, false, &cb);
+    const auto& X = std::get<0>(out);
+    const auto& U = std::get<2>(out);
+    const auto& K = std::get<3>(out);
+    const auto& d = std::get<4>(out);
+    const double cost = std::get<5>(out);
+    CHECK(cb.n == 3);
+    CHECK((int)X.size() == T && (int)U.size() == T - 1 && (int)K.size() == T - 1 && (int)d.size() == T - 1);
+    CHECK(K[0].rows == 2 && K[0].cols == 4);
+    CHECK(cost < c_init * 1e-2);
+    // the cost is the cost of the returned controls, the states are their rollout
+    CHECK(std::fabs(s->total(U) - cost) <= 1e-12 * std::fabs(cost));
+    s->reset();
+    for (int k = 0; k < T - 1; k++) {
+        for (int i = 0; i < 4; i++) CHECK(std::fabs(s->getState()[i] - X[k][i]) <= 1e-13);
+        s->forwardPass(X[k], U[k], k);
+    }
+    // stationary point of the (linear-quadratic) problem: central differences over every control entry
+    for (int k = 0; k < T - 1; k++)
+        for (int i = 0; i < 2; i++) {
+            auto Up = U, Um = U;
+            Up[k][i] += 1e-4; Um[k][i] -= 1e-4;
+            const double g = (s->total(Up) - s->total(Um)) / 2e-4;
+            CHECK(std::fabs(g) <= 1e-6);
+        }
+    // early stop needs cost < 1e-3: never here, all iterations run; without line search alpha stays 1
+    auto out2 = solver_.solve(U0, 2, false, true, &cb);
+    CHECK(std::get<5>(out2) <= cost * (1 + 1e-6) + 1e-12);
+    // everything but ILQRRecursive::solve refuses a system without device lowering
+    bool threw = false;
+    try {
+        solver::BatchInputs in;
+        in.B = 1;
+        for (auto& u : U0) in.U0.insert(in.U0.end(), u.begin(), u.end());
+        solver_.solveBatch(in, 1, true, false);
+    } catch (const std::runtime_error&) { threw = true; }
+    CHECK(threw);
+    std::printf("ok: cost %.6g -> %.6g in 3 iterations\n", c_init, cost);
+    return 0;
+}
