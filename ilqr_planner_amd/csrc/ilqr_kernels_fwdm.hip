@@ -32,7 +32,7 @@
 namespace ilqr {
 
 typedef double d4f_t __attribute__((ext_vector_type(4)));
-#define FM_TI 4
+#define FM_TI 4  // instances per wave (measured on C4, ms per 20-iteration solve: 2 -> 34.2, 4 -> 32.8, 8 -> 41.6: register spills)
 
 template <class S>
 __global__ __launch_bounds__(64) void k_forward_mfma(Bufs a, FwdArgs f) {
