@@ -47,6 +47,8 @@ def config(name: str):
                        al=dict(row=5, bound=2.0, penalty=0.25, scaling=1.1, lag=5)),
         "C4t1al": dict(kind=capi.SYS_POS_ORN_TIME, nb_deriv=1, T=100, dt=None, B=64, seed=16, Qdiag=[P + [0], P + [.1]], ctimes=[2.0, 5.0], solver="al",
                        nb_iter=10, al=dict(row=5, bound=2.0, penalty=0.25, scaling=1.1, lag=5)),
+        "C4al": dict(kind=capi.SYS_POS_ORN_TIME, nb_deriv=2, T=80, dt=None, B=48, seed=19, Qdiag=[P + V + [.1], P + V + [.1]], ctimes=[2.0, 4.0], solver="al",
+                     nb_iter=8, al=dict(row=5, bound=2.0, penalty=0.25, scaling=1.1, lag=3)),
         "C1jal": dict(kind=capi.SYS_JOINT, nb_deriv=1, T=100, dt=0.1, B=64, seed=17, dof=7, Qdiag=[[1] * 7, [1, .5, 1, .5, 1, .5, 1]], solver="al", nb_iter=8,
                       al=dict(row=5, bound=1.0, penalty=0.25, scaling=1.1, lag=3)),
         "C1tal": dict(kind=capi.SYS_JOINT_TIME, nb_deriv=1, T=60, dt=None, B=64, seed=18, dof=7, Qdiag=[[1] * 7 + [0], [1] * 7 + [.1]], ctimes=[2.0, 4.0],

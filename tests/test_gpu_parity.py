@@ -108,7 +108,7 @@ def test_tutorial_traces_on_gpu(ctx, name, idx, hip_path):
                                                        ("C1", 1, 10, "inactive"), ("C1j", 96, 8, "inactive"), ("C1j", 48, 8, "active"), ("C1t", 64, 10, "inactive"),
                                                        ("C2h", 96, 12, "inactive"), ("C2h", 48, 12, "urdf"), ("C4h", 48, 12, "inactive"),  # hybrid sequences
                                                        ("C2hl", 48, 12, "urdf"),
-                                                       ("C2ndal", 32, 10, "inactive"), ("C4t1al", 32, 10, "inactive"),  # AL on the 2nd-order and time systems
+                                                       ("C2ndal", 32, 10, "inactive"), ("C4t1al", 32, 10, "inactive"), ("C4al", 24, 8, "inactive"), ("C4al", 16, 8, "urdf"),  # AL on the 2nd-order and time systems
                                                        ("C1jal", 32, 8, "inactive"), ("C1tal", 32, 8, "inactive")])  # ... and on the joint-space systems  # ... whose sub-systems have different bounds (second limit set)  # JointSpacePlannerSys (C1 = BASELINE configs[0])
 def test_random_batch_vs_oracle(ctx, cfg_name, B, nb_iter, limits, hip_path):
     """Seeded random batches: every instance ends within 1e-4 relative of the oracle's own end-to-end run, or is PROVEN iteration by
