@@ -383,55 +383,6 @@ ILQR_DEV double cpl_cost(const DevDesc& d, const Bufs& a, const CPArgs& c, int b
 // KWP lanes per instance: lane q accumulates PSI'R u0 for its own column q (the long part of this pass: (T-1) n_u terms per column,
 // basis rows read as coalesced vector loads; with one lane per instance they are uniform -> scalar loads whose latency, one per
 // control entry, bounds the kernel).  All lanes walk the rollout of u0, lane 0 records the states at the keypoint steps.
-template <class S, int KWP>
-__global__ __launch_bounds__(64) void k_cpl_init(Bufs a, CPArgs c) {
-    constexpr int NX = S::NX, NU = S::NU, IPB = 64 / KWP;
-    static_assert(64 % KWP == 0, "KWP lanes per instance");
-    const DevDesc& d = *a.desc;
-    // XCD-aware tile index: a wave covers 64 / KWP consecutive instances = 32 bytes of every 128-byte line of U0, so four waves share each
-    // line; dealt round-robin over the XCDs (tile = blockIdx) they sat on four different L2s and every line of U0 came from HBM four
-    // times (FETCH_SIZE: 739 MB for 183 MB of controls)
-    const int q = threadIdx.x % KWP, b = xcd_tile() * IPB + threadIdx.x / KWP;
-    if (b >= d.B) return;
-    const int Bp = d.Bp, T = d.T;
-    double x[NX], xp[NX], u[NU], xn[NX], g0 = 0;
-    init_state<S>(d, a, b, x);
-    UNR for (int i = 0; i < NX; i++) xp[i] = x[i];
-    double c00 = 0;
-    int kpi = 0;
-    auto record = [&]() {
-        if (q == 0) {
-            double* xb = c.xbk + (size_t)kpi * 2 * NX * Bp;
-            UNR for (int r = 0; r < NX; r++) { AT(xb, r, b) = x[r]; AT(xb, NX + r, b) = xp[r]; }
-        }
-        kpi++;
-    };
-    if (kpi < d.n_kp && d.kp_t[kpi] == 0) record();
-#pragma unroll 4
-    for (int s = 0; s < T - 1; s++) {
-        UNR for (int i = 0; i < NU; i++) {
-            u[i] = AT(a.U0, s * NU + i, b);
-            const double ru = d.R_diag[i] * u[i];
-            c00 += u[i] * ru;
-            g0 += PSI(s * NU + i, q) * ru;
-        }
-        dyn_step<S>(d, x, u, xn);
-        UNR for (int i = 0; i < NX; i++) { xp[i] = x[i]; x[i] = xn[i]; }
-        if (kpi < d.n_kp && d.kp_t[kpi] == s + 1) record();
-    }
-    AT(c.g0, q, b) = g0;
-    AT(c.wv, q, b) = 0;
-    if (q != 0) return;
-    c.c00[b] = c00;
-    a.cur[b] = 0;
-    a.active[b] = 1;
-    a.iters[b] = 0;
-    a.status[b] = 0;
-    a.alpha[b] = 1.0;
-    a.pend[b] = 0;
-    a.pred[b] = 0;
-}
-
 // the reference's W = Su PSI at the keypoint steps is the same for all instances of an LTI system: fill the per-instance table
 // k_cp_solve reads (one lane per (instance, entry))
 __global__ void k_cpl_bcast(const double* __restrict__ wref, double* __restrict__ Wkp, int n_entries, int B, int Bp) {
@@ -514,20 +465,139 @@ __global__ __launch_bounds__(64) void k_cpl_linesearch(Bufs a, CPArgs c) {
     if (c.early_stop && alpha * sqrt(dun2 > 0 ? dun2 : 0.0) < 1e-3) a.active[b] = 0;  // :167
 }
 
-// u = u0 + PSI w, then the rollout that fills X (k_cp_final)
+// ---- the horizon walks of the coefficient-space path with one lane per (instance, coordinate) / per (instance, chunk of steps).
+// k_cpl_init (one lane per (instance, basis column), every lane rolling the whole state and reading 14 values per step) and k_cp_final (one
+// lane per instance) were chains of T - 1 steps with a memory latency per few steps: 0.44 + 0.22 ms of a 2.75 ms solve at the C5 shape.
+// For the constant-A, B systems the coordinates integrate independently, so:
+//   k_cpl_states   lane (b, i): joint i of instance b through the horizon (dyn_step's expressions on that coordinate, controls fetched in
+//                  chunks); at the keypoint steps it drops x and the state one step earlier into `xbk`.  mode 1: the final rollout -- the
+//                  controls are U[0] and every state goes to X[0].
+//   k_cpl_quad, k_cpl_controls   the two products with the basis, PSI' (R u0) and PSI w, are GEMMs over 16-instance tiles: matrix cores (below).
+template <class S>
+__global__ __launch_bounds__(256) void k_cpl_states(Bufs a, CPArgs c, int mode) {
+    constexpr int NX = S::NX, NU = S::NU, ND = S::ND, CH = 8;
+    static_assert(S::TM == 0, "constant A, B");
+    const DevDesc& d = *a.desc;
+    const int b = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (b >= d.B) return;
+    const int Bp = d.Bp, T = d.T;
+    const double dt = d.dt;
+    double q = AT(a.q0, i, b), v = (ND == 2) ? AT(a.dq0, i, b) : 0.0, qp = q, vp = v;
+    const double* __restrict__ Uin = mode ? a.U[0] : a.U0;
+    double* __restrict__ X = a.X[0];
+    int kpi = 0;
+    auto record = [&]() {  // keypoint step reached: x and the state one step earlier (limit terms act on the pre-step state)
+        double* xb = c.xbk + (size_t)kpi * 2 * NX * Bp;
+        AT(xb, i, b) = q; AT(xb, NX + i, b) = qp;
+        if (ND == 2) { AT(xb, DOF + i, b) = v; AT(xb, NX + DOF + i, b) = vp; }
+        kpi++;
+    };
+    if (!mode && kpi < d.n_kp && d.kp_t[kpi] == 0) record();
+    for (int k0 = 0; k0 < T - 1; k0 += CH) {
+        double u[CH];
+        UNR for (int j = 0; j < CH; j++) u[j] = AT(Uin, (k0 + j < T - 1 ? k0 + j : T - 2) * NU + i, b);
+        UNR for (int j = 0; j < CH; j++) {
+            const int k = k0 + j;
+            if (k >= T - 1) break;
+            if (mode) { AT(X, k * NX + i, b) = q; if (ND == 2) AT(X, k * NX + DOF + i, b) = v; }
+            qp = q; vp = v;
+            if (ND == 1) {
+                q = q + (dt * u[j] + dt * dt / 2 * 0.0);   // dyn_step, same expressions
+            } else {
+                q = q + (dt * v + dt * dt / 2 * u[j]);
+                v = v + dt * u[j];
+            }
+            if (!mode && kpi < d.n_kp && d.kp_t[kpi] == k + 1) record();
+        }
+    }
+    if (mode) { AT(X, (T - 1) * NX + i, b) = q; if (ND == 2) AT(X, (T - 1) * NX + DOF + i, b) = v; }
+}
+
+// g0 = PSI' (R u0) and c00 = u0' R u0 on the f64 matrix cores: for 16 instances, G [16 x 16] = PSI' [16 x rows] x (R u0) [rows x 16] is a
+// plain GEMM with a long inner dimension (rows = (T-1) n_u = 2793 at the C5 shape) -- four waves share it, each walking its k-steps four rows per
+// v_mfma_f64_16x16x4_f64 on two accumulators; the parts are added in wave order.  A[i = q][k = h] = PSI[row 4s + h][q] (a row of PSI is 128
+// contiguous bytes), B[k = h][j = c] = R u0 of row 4s + h, instance b0 + c (16 instances = one 128-byte line).  The VALU version (a lane per
+// instance, PSI through 112 scalar loads per step) took 0.12 ms for these 183 MB; this one is bound by reading them.
+typedef double d4c_t __attribute__((ext_vector_type(4)));
+template <class S, int KWP>
+__global__ __launch_bounds__(256) void k_cpl_quad(Bufs a, CPArgs c) {
+    static_assert(KWP == 16, "one 16-column tile");
+    constexpr int NU = S::NU, NW = 4;  // NW waves share the inner dimension of a tile (k-step s goes to wave s mod NW): 4x the loads in flight
+    __shared__ double sR[8];
+    __shared__ double sPart[NW][5][64];
+    const DevDesc& d = *a.desc;
+    const int l = threadIdx.x & 63, wv = threadIdx.x >> 6, h = l >> 4, cc = l & 15;
+    const int b = blockIdx.x * 16 + cc;  // (b < Bp: Bp is a multiple of 64)
+    const int Bp = d.Bp, T = d.T, rows = (T - 1) * NU;
+    if (threadIdx.x < NU) sR[threadIdx.x] = d.R_diag[threadIdx.x];
+    __syncthreads();
+    d4c_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+    double c00 = 0;
+    const int nk = (rows + 3) / 4;
+    int rm = (4 * wv + h) % NU;  // (4 s + h) mod n_u along s = wv, wv + NW, ...
+    auto kstep = [&](int s, d4c_t& acc) {
+        const int row = 4 * s + h;
+        const bool ok = row < rows;
+        const int rc = ok ? row : rows - 1;
+        const double ps = PSI(rc, cc), u = AT(a.U0, rc, b), ru = sR[rm] * u;
+        rm += (4 * NW) % NU; if (rm >= NU) rm -= NU;
+        c00 = fma(ok ? u : 0.0, ru, c00);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ok ? ps : 0.0, ok ? ru : 0.0, acc, 0, 0, 0);
+    };
+    for (int s0 = wv; s0 < nk; s0 += 8 * NW) {  // (k-steps beyond the end multiply zeros)
+        UNR for (int j = 0; j < 8; j += 2) { kstep(s0 + j * NW, acc0); kstep(s0 + (j + 1) * NW, acc1); }
+    }
+    c00 += __shfl_xor(c00, 16);
+    c00 += __shfl_xor(c00, 32);
+    UNR for (int r = 0; r < 4; r++) sPart[wv][r][l] = acc0[r] + acc1[r];
+    sPart[wv][4][l] = c00;
+    __syncthreads();
+    if (wv != 0 || b >= d.B) return;
+    UNR for (int r = 0; r < 4; r++) {  // D[row = h + 4 r][col = cc]: column q = h + 4 r of the basis, instance b; the waves' parts in wave order
+        double g = sPart[0][r][l];
+        UNR for (int w_ = 1; w_ < NW; w_++) g += sPart[w_][r][l];
+        AT(c.g0, h + 4 * r, b) = g;
+        AT(c.wv, h + 4 * r, b) = 0;
+    }
+    if (h == 0) {
+        double cs = sPart[0][4][l];
+        UNR for (int w_ = 1; w_ < NW; w_++) cs += sPart[w_][4][l];
+        c.c00[b] = cs;
+        a.cur[b] = 0;
+        a.active[b] = 1;
+        a.iters[b] = 0;
+        a.status[b] = 0;
+        a.alpha[b] = 1.0;
+        a.pend[b] = 0;
+        a.pred[b] = 0;
+    }
+}
+
+// u = u0 + PSI w for 16 instances: PSI [rows x 16] x W [16 x 16], one 16-row tile of PSI per four MFMAs, W held in registers for the whole walk
 template <class S, int KWP>
 __global__ __launch_bounds__(64) void k_cpl_controls(Bufs a, CPArgs c) {
+    static_assert(KWP == 16, "one 16-column tile");
     constexpr int NU = S::NU;
     const DevDesc& d = *a.desc;
-    const int b = blockIdx.x * 64 + threadIdx.x, s = blockIdx.y;
-    if (b >= d.B) return;
-    const int Bp = d.Bp;
-    double w[KWP];
-    UNR for (int q = 0; q < KWP; q++) w[q] = AT(c.wv, q, b);
-    UNR for (int i = 0; i < NU; i++) {
-        double du = 0;
-        UNR for (int q = 0; q < KWP; q++) du += PSI(s * NU + i, q) * w[q];
-        AT(a.U[0], s * NU + i, b) = AT(a.U0, s * NU + i, b) + du;
+    const int l = threadIdx.x, h = l >> 4, cc = l & 15;
+    const int b = blockIdx.x * 16 + cc;
+    const int Bp = d.Bp, T = d.T, rows = (T - 1) * NU;
+    const int nt = (rows + 15) / 16, t0 = blockIdx.y * 16, t1 = (t0 + 16 < nt) ? t0 + 16 : nt;  // 16 tiles (256 rows) per wave
+    double wq[4];
+    UNR for (int s = 0; s < 4; s++) wq[s] = AT(c.wv, 4 * s + h, b);  // B[k = h][j = cc] of k-step s: w_{4s+h} of instance b
+    for (int t = t0; t < t1; t++) {
+        const int ra = 16 * t + cc;          // A[i = cc][k = h]: row ra of PSI, column 4 s + h
+        const bool oka = ra < rows;
+        const int rac = oka ? ra : rows - 1;
+        d4c_t acc = {0, 0, 0, 0};
+        UNR for (int s = 0; s < 4; s++) {
+            const double ps = PSI(rac, 4 * s + h);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(oka ? ps : 0.0, wq[s], acc, 0, 0, 0);
+        }
+        UNR for (int r = 0; r < 4; r++) {    // D[row = h + 4 r][col = cc]
+            const int row = 16 * t + h + 4 * r;
+            if (row < rows && b < d.B) AT(a.U[0], row, b) = AT(a.U0, row, b) + acc[r];
+        }
     }
 }
 
@@ -642,7 +712,8 @@ static int run_cpl(BatchCPState& st, const DevDesc& h, Bufs& bufs, const std::ve
     c.wref = st.wref;
     const bool wave_solve = !(std::getenv("ILQR_CP_SOLVE") && !std::strcmp(std::getenv("ILQR_CP_SOLVE"), "lane"));  // cross-check: lane per instance
     ph(ILQR_PROF_ROLLOUT);   // rollout of u0, its keypoint states and the quadratic forms of the control cost (walks the horizon)
-    hipLaunchKernelGGL((k_cpl_init<S, KWP>), dim3(grid_x8((B + 64 / KWP - 1) / (64 / KWP))), dim3(64), 0, stream, bufs, c);
+    hipLaunchKernelGGL((k_cpl_states<S>), dim3((B + 255) / 256, DOF), dim3(256), 0, stream, bufs, c, 0);
+    hipLaunchKernelGGL((k_cpl_quad<S, KWP>), dim3((B + 15) / 16), dim3(256), 0, stream, bufs, c);
     if (nkp > 0) hipLaunchKernelGGL(k_cpl_bcast, dim3((B + 255) / 256, nkp * NX * KWP), dim3(256), 0, stream, st.wref, st.Wkp, nkp * NX * KWP, B, h.Bp);
     for (int it = 0; it < nb_iter; it++) {
         c.it = it;
@@ -654,8 +725,8 @@ static int run_cpl(BatchCPState& st, const DevDesc& h, Bufs& bufs, const std::ve
         hipLaunchKernelGGL((k_cpl_linesearch<S, KWP>), dim3((B + 3) / 4), dim3(64), 0, stream, bufs, c);
     }
     ph(ILQR_PROF_APPLY);     // u = u0 + PSI w and the final rollout (walks the horizon)
-    hipLaunchKernelGGL((k_cpl_controls<S, KWP>), dim3((B + 63) / 64, T - 1), dim3(64), 0, stream, bufs, c);
-    hipLaunchKernelGGL((k_cp_final<S>), grid, block, 0, stream, bufs);
+    hipLaunchKernelGGL((k_cpl_controls<S, KWP>), dim3((B + 15) / 16, ((T - 1) * S::NU + 255) / 256), dim3(64), 0, stream, bufs, c);
+    hipLaunchKernelGGL((k_cpl_states<S>), dim3((B + 255) / 256, DOF), dim3(256), 0, stream, bufs, c, 1);
     if (hipGetLastError() != hipSuccess) { err = "ilqr_solve_batch_cp: kernel launch failed"; return 1; }
     return 0;
 }
