@@ -104,11 +104,11 @@ def algorithmic_bytes(cfg, nx, nu, m, B, fused):
     Riccati solvers, per instance-step:  backward reads xbar, ubar (+ lambda, I_k) and writes K, d -- the fused sweep also reads x(1), u(1)
     and writes the accepted x, u (the APPLY pass it replaces), and neither reads nor writes I_k;  forward = ONE pass over K, d, xbar, ubar
     + write of x(1), u(1) whatever the number of step sizes.
-    Batch-CP in coefficient space, per instance and SOLVE: the horizon is walked by the first kernel (reads U0) and by the last two
-    (write U, X); an iteration touches keypoint-sized data only."""
+    Batch-CP in coefficient space, per instance and SOLVE: the horizon is walked at the start (reads U0: keypoint states and the quadratic
+    forms of the control cost) and at the end (reads U0, writes U = U0 + PSI w and X); an iteration touches keypoint-sized data only."""
     T = cfg["T"]
     if cfg["solver"] == "batch_cp":
-        return dict(rollout=8 * (T - 1) * nu * B, apply=8 * ((T - 1) * nu + T * nx) * B, backward=None, forward=None)
+        return dict(rollout=8 * (T - 1) * nu * B, apply=8 * (2 * (T - 1) * nu + T * nx) * B, backward=None, forward=None)
     steps = (T - 1) * B
     bwd = 8 * ((nx + nu) + (nu * nx + nu) + (m if fused else 2 * m)) * steps
     if fused:
