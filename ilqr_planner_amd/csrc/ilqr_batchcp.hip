@@ -470,11 +470,11 @@ __global__ __launch_bounds__(64) void k_cpl_linesearch(Bufs a, CPArgs c) {
 // lane per instance) were chains of T - 1 steps with a memory latency per few steps: 0.44 + 0.22 ms of a 2.75 ms solve at the C5 shape.
 // For the constant-A, B systems the coordinates integrate independently, so:
 //   k_cpl_states   lane (b, i): joint i of instance b through the horizon (dyn_step's expressions on that coordinate, controls fetched in
-//                  chunks); at the keypoint steps it drops x and the state one step earlier into `xbk`.  mode 1: the final rollout -- the
-//                  controls are U[0] and every state goes to X[0].
+//                  chunks); at the keypoint steps it drops x and the state one step earlier into `xbk`.  k_cpl_final: the final rollout --
+//                  the controls are U[0] and every state goes to X[0].
 //   k_cpl_quad, k_cpl_controls   the two products with the basis, PSI' (R u0) and PSI w, are GEMMs over 16-instance tiles: matrix cores (below).
-template <class S>
-__global__ __launch_bounds__(256) void k_cpl_states(Bufs a, CPArgs c, int mode) {
+template <class S, int mode>
+ILQR_DEV void cpl_walk(const Bufs& a, const CPArgs& c) {
     constexpr int NX = S::NX, NU = S::NU, ND = S::ND, CH = 8;
     static_assert(S::TM == 0, "constant A, B");
     const DevDesc& d = *a.desc;
@@ -512,6 +512,10 @@ __global__ __launch_bounds__(256) void k_cpl_states(Bufs a, CPArgs c, int mode) 
     }
     if (mode) { AT(X, (T - 1) * NX + i, b) = q; if (ND == 2) AT(X, (T - 1) * NX + DOF + i, b) = v; }
 }
+template <class S>
+__global__ __launch_bounds__(256) void k_cpl_states(Bufs a, CPArgs c) { cpl_walk<S, 0>(a, c); }  // rollout of u0: keypoint states
+template <class S>
+__global__ __launch_bounds__(256) void k_cpl_final(Bufs a, CPArgs c) { cpl_walk<S, 1>(a, c); }   // rollout of the solution: X out
 
 // g0 = PSI' (R u0) and c00 = u0' R u0 on the f64 matrix cores: for 16 instances, G [16 x 16] = PSI' [16 x rows] x (R u0) [rows x 16] is a
 // plain GEMM with a long inner dimension (rows = (T-1) n_u = 2793 at the C5 shape) -- four waves share it, each walking its k-steps four rows per
@@ -712,7 +716,7 @@ static int run_cpl(BatchCPState& st, const DevDesc& h, Bufs& bufs, const std::ve
     c.wref = st.wref;
     const bool wave_solve = !(std::getenv("ILQR_CP_SOLVE") && !std::strcmp(std::getenv("ILQR_CP_SOLVE"), "lane"));  // cross-check: lane per instance
     ph(ILQR_PROF_ROLLOUT);   // rollout of u0, its keypoint states and the quadratic forms of the control cost (walks the horizon)
-    hipLaunchKernelGGL((k_cpl_states<S>), dim3((B + 255) / 256, DOF), dim3(256), 0, stream, bufs, c, 0);
+    hipLaunchKernelGGL((k_cpl_states<S>), dim3((B + 255) / 256, DOF), dim3(256), 0, stream, bufs, c);
     hipLaunchKernelGGL((k_cpl_quad<S, KWP>), dim3((B + 15) / 16), dim3(256), 0, stream, bufs, c);
     if (nkp > 0) hipLaunchKernelGGL(k_cpl_bcast, dim3((B + 255) / 256, nkp * NX * KWP), dim3(256), 0, stream, st.wref, st.Wkp, nkp * NX * KWP, B, h.Bp);
     for (int it = 0; it < nb_iter; it++) {
@@ -726,7 +730,7 @@ static int run_cpl(BatchCPState& st, const DevDesc& h, Bufs& bufs, const std::ve
     }
     ph(ILQR_PROF_APPLY);     // u = u0 + PSI w and the final rollout (walks the horizon)
     hipLaunchKernelGGL((k_cpl_controls<S, KWP>), dim3((B + 15) / 16, ((T - 1) * S::NU + 255) / 256), dim3(64), 0, stream, bufs, c);
-    hipLaunchKernelGGL((k_cpl_states<S>), dim3((B + 255) / 256, DOF), dim3(256), 0, stream, bufs, c, 1);
+    hipLaunchKernelGGL((k_cpl_final<S>), dim3((B + 255) / 256, DOF), dim3(256), 0, stream, bufs, c);
     if (hipGetLastError() != hipSuccess) { err = "ilqr_solve_batch_cp: kernel launch failed"; return 1; }
     return 0;
 }
