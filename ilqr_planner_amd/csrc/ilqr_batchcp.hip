@@ -337,7 +337,8 @@ __global__ __launch_bounds__(LPB) void k_cp_final(Bufs a) {
 //     sum_k u_k' R u_k = u0'R u0 + 2 w.(PSI'R u0) + w'(PSI'R PSI) w,   ||PSI dw||^2 = dw'(PSI'PSI) dw,   PSI'R u = PSI'R u0 + (PSI'R PSI) w
 // so an iteration needs the states at the keypoint steps only: no pass over the horizon at all.  The shifted W = Su PSI of the
 // reference (what H and g are built from, quirk D-1) is the same for every instance and is broadcast once; k_cp_solve is shared
-// with the general path.  The horizon is walked twice per solve: k_cpl_init (rollout of u0) and k_cpl_final (u, X out).
+// with the general path.  The horizon is walked at the start of a solve (k_cpl_states, k_cpl_quad: rollout of u0 and the quadratic forms of its cost) and at its end
+// (k_cpl_controls, k_cpl_final: u and X out).
 #define WT(kp, which, r, q) c.wt[((((size_t)(kp) * 2 + (which)) * NX + (r)) * KWP) + (q)]
 
 template <class S, int KWP>
@@ -466,7 +467,7 @@ __global__ __launch_bounds__(64) void k_cpl_linesearch(Bufs a, CPArgs c) {
 }
 
 // ---- the horizon walks of the coefficient-space path with one lane per (instance, coordinate) / per (instance, chunk of steps).
-// k_cpl_init (one lane per (instance, basis column), every lane rolling the whole state and reading 14 values per step) and k_cp_final (one
+// The first versions (one lane per (instance, basis column), every lane rolling the whole state and reading 14 values per step; k_cp_final: one
 // lane per instance) were chains of T - 1 steps with a memory latency per few steps: 0.44 + 0.22 ms of a 2.75 ms solve at the C5 shape.
 // For the constant-A, B systems the coordinates integrate independently, so:
 //   k_cpl_states   lane (b, i): joint i of instance b through the horizon (dyn_step's expressions on that coordinate, controls fetched in

@@ -1,6 +1,6 @@
 // ilqr_kernels_mfma.hip -- wave-per-instance backward Riccati sweep with the dense products on the f64 matrix cores
 //
-// Same step as k_backward_gen (ilqr_kernels_gen.hip; ILQRRecursive.cpp:68-97, AL terms AL-ILQR.cpp:110-134), re-mapped so that
+// The Riccati step of ILQRRecursive.cpp:68-97 (AL terms AL-ILQR.cpp:110-134) for every system kind, mapped so that
 // the three genuinely dense products of a step run as v_mfma_f64_16x16x4_f64 and chain through registers.  Everything is
 // carried with ONE extra "affine" column NX (all systems have n_x <= 15):
 //     Qux~ = [Qux | Qu]   K~ = [K | d] = Quu_inv Qux~   T1~ = Quu K~ + Qux~ = [Quu K + Qux | Quu d + Qu]
@@ -10,7 +10,7 @@
 //     K~  = S (LDS)  x Qux~ (registers, "U-map": lane owns control rows h, h+4 of column c)
 //     T1~ = Quu (LDS) x K~ (D registers of the first product) + Qux~
 //     P~' = K~^T T1~ (both D registers) + Qxu (registers: the U-map transposed) x K~ + [Qxx | Qx] ("P-map": rows h+4r, column c)
-// No LDS traffic at all for the products (k_backward_gen spent 250 of its 410 LDS instructions per step there and is bound by
+// No LDS traffic at all for the products (the LDS-based predecessor of this kernel, removed, spent 250 of its 410 LDS instructions per step there and was bound by
 // LDS bandwidth).  What is left in LDS: P (read entrywise for the structured A^T P A, B^T P, ...), B^T P, the Quu sweep, and
 // the few vectors.  The time column of B needs dot products with P and B^T P: they are split over all 64 lanes and reduced
 // with lane shuffles instead of being walked by the 16 lanes that own the results.

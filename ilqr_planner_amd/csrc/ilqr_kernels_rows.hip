@@ -69,7 +69,7 @@ __global__ __launch_bounds__(64) void k_forward_lin(Bufs a, FwdArgs f) {
 
     constexpr int NS = PF + 1;  // ring slots: the slot consumed in step k-1 receives step k+PF-1 ... no register copies, distance PF
     double ring[NS][NLD];
-    auto fetch = [&](int slot, int k) {  // unconditional (see k_forward_rows); pointers stop at the last timestep
+    auto fetch = [&](int slot, int k) {  // unconditional (a CFG path that skips a load makes the waitcnt pass fall back to vmcnt(0)); pointers stop at the last timestep
         UNR for (int q = 0; q < ROWP / 2; q++) {  // 16-byte loads
             const double2 v2 = reinterpret_cast<const double2*>(pK)[q];
             ring[slot][2 * q] = v2.x;
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(64) void k_forward_lin(Bufs a, FwdArgs f) {
     double xT[ND];  // xbar_{T-1} of this lane's coordinates (terminal step)
     UNR for (int q = 0; q < ND; q++) xT[q] = AT(a.X[cur], (T - 1) * NX + q * DOF + r, bb);
     __builtin_amdgcn_sched_barrier(0);
-    UNR for (int q = 0; q < PF; q++) { fetch(q, q); __builtin_amdgcn_sched_barrier(0); }  // in issue order (see k_forward_rows)
+    UNR for (int q = 0; q < PF; q++) { fetch(q, q); __builtin_amdgcn_sched_barrier(0); }  // in issue order (vmcnt)
 
     double dxq = 0, dxd = 0, pc[NA];
     UNR for (int al = 0; al < NA; al++) pc[al] = 0;
