@@ -200,7 +200,7 @@ template <class S, int KWP>
 __global__ __launch_bounds__(64) void k_cp_solve_w(Bufs a, CPArgs c) {
     constexpr int NX = S::NX;
     __shared__ double Hs[KWP][KWP + 2], Ws[NX][KWP], Cs[NX][NX], CWs[NX][KWP], rs[NX], xs[KWP];
-    __shared__ int prS;
+    __shared__ double mulS[KWP];
     const DevDesc& d = *a.desc;
     const int lane = threadIdx.x, b = blockIdx.x;
     if (!a.active[b]) return;  // uniform: one instance per workgroup
@@ -236,23 +236,25 @@ __global__ __launch_bounds__(64) void k_cp_solve_w(Bufs a, CPArgs c) {
         }
     }
     __syncthreads();
-    for (int k = 0; k < KWP; k++) {  // partial-pivot LU (Eigen PartialPivLU), lane q owns column q; column KWP = right-hand side
-        if (lane == 0) {
-            int pr = k;
-            double best = fabs(Hs[k][k]);
-            for (int i = k + 1; i < KWP; i++) {
-                const double v = fabs(Hs[i][k]);
-                if (v > best) { best = v; pr = i; }
-            }
-            prS = pr;
-        }
-        __syncthreads();
-        const int pr = prS;
+    UNR for (int k = 0; k < KWP; k++) {  // partial-pivot LU (Eigen PartialPivLU), lane q owns column q; column KWP = right-hand side
+        // (unrolled over the pivots: the rows of an elimination step are independent LDS read-modify-writes the compiler can then batch)
+        // pivot = FIRST row with the largest |H[i][k]|, i >= k: lane i holds its candidate, a butterfly finds the maximum, a ballot the first lane
+        // that holds it (the serial scan by one lane was 15 dependent LDS reads per pivot)
+        const bool cand = lane >= k && lane < KWP;
+        const double av = cand ? fabs(Hs[cand ? lane : k][k]) : -1.0;
+        double mx = av;
+        UNR for (int o = 1; o < 32; o <<= 1) mx = fmax(mx, __shfl_xor(mx, o));  // (KWP <= 32 lanes hold candidates; NaN candidates lose as in the scan)
+        mx = fmax(mx, __shfl_xor(mx, 32));
+        const unsigned long long eq = __ballot((cand && av == mx) ? 1 : 0);
+        const int pr = (eq && !isnan(Hs[k][k])) ? (__ffsll((long long)eq) - 1) : k;  // (a NaN on the diagonal stays the pivot: nothing compares greater)
         if (lane <= KWP && lane >= k && pr != k) { const double t0 = Hs[k][lane]; Hs[k][lane] = Hs[pr][lane]; Hs[pr][lane] = t0; }
         __syncthreads();
+        // multipliers H[i][k] / pivot once per row (lane i), not once per entry: every lane of a column divided all 15 of them itself
+        if (lane > k && lane < KWP) mulS[lane] = Hs[lane][k] / Hs[k][k];
+        __syncthreads();
         if (lane <= KWP && lane > k) {
-            const double pv = Hs[k][k], hk = Hs[k][lane];
-            for (int i = k + 1; i < KWP; i++) Hs[i][lane] -= (Hs[i][k] / pv) * hk;
+            const double hk = Hs[k][lane];
+            UNR for (int i = k + 1; i < KWP; i++) Hs[i][lane] -= mulS[i] * hk;
         }
         __syncthreads();
     }
