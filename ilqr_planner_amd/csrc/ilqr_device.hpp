@@ -222,28 +222,24 @@ ILQR_DEV void eig_quat_to_mat(const double* q, double* m) {
     m[6] = txz - twy; m[7] = tyz + twx; m[8] = 1 - (txx + tyy);
 }
 ILQR_DEV void eig_mat_to_quat(const double* m, double* q) {
-    double t = m[0] + m[4] + m[8];
-    if (t > 0) {
-        t = sqrt(t + 1.0);
-        q[0] = 0.5 * t;
-        t = 0.5 / t;
-        q[1] = (m[7] - m[5]) * t; q[2] = (m[2] - m[6]) * t; q[3] = (m[3] - m[1]) * t;
-    } else if (m[0] >= m[4] && m[0] >= m[8]) {  // i = 0 (ties resolve as Eigen's strict '>' comparisons do)
-        t = sqrt(m[0] - m[4] - m[8] + 1.0);
-        q[1] = 0.5 * t;
-        t = 0.5 / t;
-        q[0] = (m[7] - m[5]) * t; q[2] = (m[3] + m[1]) * t; q[3] = (m[6] + m[2]) * t;
-    } else if (m[4] > m[0] && m[4] >= m[8]) {   // i = 1
-        t = sqrt(m[4] - m[8] - m[0] + 1.0);
-        q[2] = 0.5 * t;
-        t = 0.5 / t;
-        q[0] = (m[2] - m[6]) * t; q[3] = (m[7] + m[5]) * t; q[1] = (m[1] + m[3]) * t;
-    } else {                                    // i = 2
-        t = sqrt(m[8] - m[0] - m[4] + 1.0);
-        q[3] = 0.5 * t;
-        t = 0.5 / t;
-        q[0] = (m[3] - m[1]) * t; q[1] = (m[2] + m[6]) * t; q[2] = (m[5] + m[7]) * t;
-    }
+    // Eigen's Quaternion(Matrix3) (the four cases by the trace and the largest diagonal entry; ties resolve as its strict '>' comparisons do),
+    // written without branches: ONE square root and ONE division on a selected radicand, the components by selects.  Same operations on
+    // the same operands as the four-way branch -- whose merged tails the compiler turned into a dynamically indexed q[], i.e. scratch (or,
+    // promoted, hidden LDS) in every kernel that holds FK.
+    const double tr = m[0] + m[4] + m[8];
+    const bool c0 = tr > 0;
+    const bool c1 = !c0 && (m[0] >= m[4] && m[0] >= m[8]);
+    const bool c2 = !c0 && !c1 && (m[4] > m[0] && m[4] >= m[8]);
+    const double r0 = tr + 1.0, r1 = m[0] - m[4] - m[8] + 1.0, r2 = m[4] - m[8] - m[0] + 1.0, r3 = m[8] - m[0] - m[4] + 1.0;
+    const double t = sqrt(c0 ? r0 : (c1 ? r1 : (c2 ? r2 : r3)));
+    const double hf = 0.5 * t, ti = 0.5 / t;
+    const double d75 = m[7] - m[5], d26 = m[2] - m[6], d31 = m[3] - m[1], s31 = m[3] + m[1], s62 = m[6] + m[2], s75 = m[7] + m[5];
+    // case:    0: q = (hf, d75 ti, d26 ti, d31 ti)   1: (d75 ti, hf, s31 ti, s62 ti)   2: (d26 ti, (m1+m3) ti, hf, s75 ti)   3: (d31 ti, (m2+m6) ti, (m5+m7) ti, hf)
+    const double s13 = m[1] + m[3], s26 = m[2] + m[6], s57 = m[5] + m[7];
+    q[0] = c0 ? hf : ((c1 ? d75 : (c2 ? d26 : d31)) * ti);
+    q[1] = c1 ? hf : ((c0 ? d75 : (c2 ? s13 : s26)) * ti);
+    q[2] = c2 ? hf : ((c0 ? d26 : (c1 ? s31 : s57)) * ti);
+    q[3] = (c0 || c1 || c2) ? ((c0 ? d31 : (c1 ? s62 : s75)) * ti) : hf;
 }
 
 // f(x) of getFxJac: [p; quat (; dp; dquat) (; t)]  and the 6x7 Jacobian block (the full J is blkdiag(J,J) bordered by 1)

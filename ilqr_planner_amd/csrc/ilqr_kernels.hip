@@ -544,7 +544,7 @@ __global__ void k_track(Bufs a, const double* __restrict__ x_meas, int k, int wi
 
 // f(X) for every (instance, timestep): one lane per pair (tuple<1> of ILQRRecursive::solve)
 template <class S>
-__global__ void k_fx_all(Bufs a, double* __restrict__ out /* natural [B][T][NF] */) {
+__global__ __launch_bounds__(64) void k_fx_all(Bufs a, double* __restrict__ out /* natural [B][T][NF] */) {
     const DevDesc& d = *a.desc;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     const int t = blockIdx.y;
@@ -558,7 +558,7 @@ __global__ void k_fx_all(Bufs a, double* __restrict__ out /* natural [B][T][NF] 
 }
 
 // stand-alone batched FK (KDLRobot::updateKinematics), natural layouts
-__global__ void k_fk_batch(const DevDesc* dd, int n, const double* __restrict__ q, double* __restrict__ pos, double* __restrict__ quat,
+__global__ __launch_bounds__(64) void k_fk_batch(const DevDesc* dd, int n, const double* __restrict__ q, double* __restrict__ pos, double* __restrict__ quat,
                            double* __restrict__ jac) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
