@@ -340,7 +340,7 @@ __global__ __launch_bounds__(LPB) void k_cp_final(Bufs a) {
 // so an iteration needs the states at the keypoint steps only: no pass over the horizon at all.  The shifted W = Su PSI of the
 // reference (what H and g are built from, quirk D-1) is the same for every instance and is broadcast once; k_cp_solve is shared
 // with the general path.  The horizon is walked at the start of a solve (k_cpl_states, k_cpl_quad: rollout of u0 and the quadratic forms of its cost) and at its end
-// (k_cpl_controls, k_cpl_final: u and X out).
+// (k_cpl_final: u and X out).
 #define WT(kp, which, r, q) c.wt[((((size_t)(kp) * 2 + (which)) * NX + (r)) * KWP) + (q)]
 
 template <class S, int KWP>
@@ -475,34 +475,72 @@ __global__ __launch_bounds__(64) void k_cpl_linesearch(Bufs a, CPArgs c) {
 //   k_cpl_states   lane (b, i): joint i of instance b through the horizon (dyn_step's expressions on that coordinate, controls fetched in
 //                  chunks); at the keypoint steps it drops x and the state one step earlier into `xbk`.  k_cpl_final: the final rollout --
 //                  the controls are U[0] and every state goes to X[0].
-//   k_cpl_quad, k_cpl_controls   the two products with the basis, PSI' (R u0) and PSI w, are GEMMs over 16-instance tiles: matrix cores (below).
-template <class S, int mode>
+//   k_cpl_quad     PSI' (R u0) and u0' R u0: a GEMM over 16-instance tiles with a long inner dimension, on the matrix cores (below).
+//   k_cpl_final    forms u = u0 + PSI w for its coordinate on the way (the rows of PSI it needs are uniform over a block): one pass reads U0 and
+//                  writes U and X (a separate controls kernel -- also tried as a GEMM on the matrix cores, 0.089 ms -- made the rollout read U back).
+template <class S, int mode, int KWP>
 ILQR_DEV void cpl_walk(const Bufs& a, const CPArgs& c) {
-    constexpr int NX = S::NX, NU = S::NU, ND = S::ND, CH = 8;
+    constexpr int NX = S::NX, NU = S::NU, ND = S::ND, CH = 8, TILE = 64;  // TILE steps of the basis per LDS image (final pass)
     static_assert(S::TM == 0, "constant A, B");
     const DevDesc& d = *a.desc;
-    const int b = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
-    if (b >= d.B) return;
+    const int i = blockIdx.y;
+    const bool live = (int)(blockIdx.x * 256 + threadIdx.x) < d.B;
+    const int b = live ? blockIdx.x * 256 + threadIdx.x : d.B - 1;  // lanes past the batch walk the last instance and store nothing
     const int Bp = d.Bp, T = d.T;
     const double dt = d.dt;
     double q = AT(a.q0, i, b), v = (ND == 2) ? AT(a.dq0, i, b) : 0.0, qp = q, vp = v;
-    const double* __restrict__ Uin = mode ? a.U[0] : a.U0;
+    const double* __restrict__ Uin = a.U0;
     double* __restrict__ X = a.X[0];
+    double* __restrict__ Uout = a.U[0];
+    // final pass: u = u0 + PSI w is formed here.  Row s n_u + i of PSI is the same for the whole block (blockIdx.y = i): the block keeps
+    // TILE steps of it in LDS (two images, filled one tile ahead) and every lane reads them as broadcasts.
+    __shared__ double sPsi[mode ? 2 : 1][mode ? TILE : 1][mode ? KWP : 1];
+    double w[KWP];
+    auto fill = [&](int tile) {
+        if (!mode) return;
+        for (int e = threadIdx.x; e < TILE * KWP; e += 256) {
+            const int k = tile * TILE + e / KWP;
+            sPsi[tile & 1][e / KWP][e % KWP] = (k < T - 1) ? c.psi[(size_t)(k * NU + i) * KWP + e % KWP] : 0.0;
+        }
+    };
+    if (mode) {
+        UNR for (int qq = 0; qq < KWP; qq++) w[qq] = AT(c.wv, qq, b);
+        fill(0);
+    }
     int kpi = 0;
+    int kp_next = (!mode && d.n_kp > 0) ? __builtin_amdgcn_readfirstlane(d.kp_t[0]) : -1;  // wave-uniform: a scalar compare per step
     auto record = [&]() {  // keypoint step reached: x and the state one step earlier (limit terms act on the pre-step state)
         double* xb = c.xbk + (size_t)kpi * 2 * NX * Bp;
-        AT(xb, i, b) = q; AT(xb, NX + i, b) = qp;
-        if (ND == 2) { AT(xb, DOF + i, b) = v; AT(xb, NX + DOF + i, b) = vp; }
-        kpi++;
+        if (live) {
+            AT(xb, i, b) = q; AT(xb, NX + i, b) = qp;
+            if (ND == 2) { AT(xb, DOF + i, b) = v; AT(xb, NX + DOF + i, b) = vp; }
+        }
+        kpi = __builtin_amdgcn_readfirstlane(kpi + 1);
+        kp_next = (kpi < d.n_kp) ? __builtin_amdgcn_readfirstlane(d.kp_t[kpi]) : -1;
     };
-    if (!mode && kpi < d.n_kp && d.kp_t[kpi] == 0) record();
+    if (!mode && kp_next == 0) record();
+    double un[CH];  // controls of the next chunk, loaded one chunk ahead
+    UNR for (int j = 0; j < CH; j++) un[j] = AT(Uin, (j < T - 1 ? j : T - 2) * NU + i, b);
     for (int k0 = 0; k0 < T - 1; k0 += CH) {
         double u[CH];
-        UNR for (int j = 0; j < CH; j++) u[j] = AT(Uin, (k0 + j < T - 1 ? k0 + j : T - 2) * NU + i, b);
+        UNR for (int j = 0; j < CH; j++) u[j] = un[j];
+        UNR for (int j = 0; j < CH; j++) un[j] = AT(Uin, (k0 + CH + j < T - 1 ? k0 + CH + j : T - 2) * NU + i, b);
+        if (mode && k0 % TILE == 0) {
+            __syncthreads();             // image k0 / TILE is complete; the other one is no longer read
+            fill(k0 / TILE + 1);
+        }
         UNR for (int j = 0; j < CH; j++) {
             const int k = k0 + j;
             if (k >= T - 1) break;
-            if (mode) { AT(X, k * NX + i, b) = q; if (ND == 2) AT(X, k * NX + DOF + i, b) = v; }
+            if (mode) {
+                double du = 0;
+                UNR for (int qq = 0; qq < KWP; qq++) du += sPsi[(k0 / TILE) & 1][(k0 % TILE) + j][qq] * w[qq];
+                u[j] = u[j] + du;
+                if (live) {
+                    AT(X, k * NX + i, b) = q; if (ND == 2) AT(X, k * NX + DOF + i, b) = v;
+                    AT(Uout, k * NU + i, b) = u[j];
+                }
+            }
             qp = q; vp = v;
             if (ND == 1) {
                 q = q + (dt * u[j] + dt * dt / 2 * 0.0);   // dyn_step, same expressions
@@ -510,15 +548,15 @@ ILQR_DEV void cpl_walk(const Bufs& a, const CPArgs& c) {
                 q = q + (dt * v + dt * dt / 2 * u[j]);
                 v = v + dt * u[j];
             }
-            if (!mode && kpi < d.n_kp && d.kp_t[kpi] == k + 1) record();
+            if (!mode && kp_next == k + 1) record();
         }
     }
-    if (mode) { AT(X, (T - 1) * NX + i, b) = q; if (ND == 2) AT(X, (T - 1) * NX + DOF + i, b) = v; }
+    if (mode && live) { AT(X, (T - 1) * NX + i, b) = q; if (ND == 2) AT(X, (T - 1) * NX + DOF + i, b) = v; }
 }
 template <class S>
-__global__ __launch_bounds__(256) void k_cpl_states(Bufs a, CPArgs c) { cpl_walk<S, 0>(a, c); }  // rollout of u0: keypoint states
-template <class S>
-__global__ __launch_bounds__(256) void k_cpl_final(Bufs a, CPArgs c) { cpl_walk<S, 1>(a, c); }   // rollout of the solution: X out
+__global__ __launch_bounds__(256) void k_cpl_states(Bufs a, CPArgs c) { cpl_walk<S, 0, 1>(a, c); }  // rollout of u0: keypoint states
+template <class S, int KWP>
+__global__ __launch_bounds__(256) void k_cpl_final(Bufs a, CPArgs c) { cpl_walk<S, 1, KWP>(a, c); }  // u = u0 + PSI w and its rollout: U, X out
 
 // g0 = PSI' (R u0) and c00 = u0' R u0 on the f64 matrix cores: for 16 instances, G [16 x 16] = PSI' [16 x rows] x (R u0) [rows x 16] is a
 // plain GEMM with a long inner dimension (rows = (T-1) n_u = 2793 at the C5 shape) -- four waves share it, each walking its k-steps four rows per
@@ -577,34 +615,6 @@ __global__ __launch_bounds__(256) void k_cpl_quad(Bufs a, CPArgs c) {
         a.alpha[b] = 1.0;
         a.pend[b] = 0;
         a.pred[b] = 0;
-    }
-}
-
-// u = u0 + PSI w for 16 instances: PSI [rows x 16] x W [16 x 16], one 16-row tile of PSI per four MFMAs, W held in registers for the whole walk
-template <class S, int KWP>
-__global__ __launch_bounds__(64) void k_cpl_controls(Bufs a, CPArgs c) {
-    static_assert(KWP == 16, "one 16-column tile");
-    constexpr int NU = S::NU;
-    const DevDesc& d = *a.desc;
-    const int l = threadIdx.x, h = l >> 4, cc = l & 15;
-    const int b = blockIdx.x * 16 + cc;
-    const int Bp = d.Bp, T = d.T, rows = (T - 1) * NU;
-    const int nt = (rows + 15) / 16, t0 = blockIdx.y * 16, t1 = (t0 + 16 < nt) ? t0 + 16 : nt;  // 16 tiles (256 rows) per wave
-    double wq[4];
-    UNR for (int s = 0; s < 4; s++) wq[s] = AT(c.wv, 4 * s + h, b);  // B[k = h][j = cc] of k-step s: w_{4s+h} of instance b
-    for (int t = t0; t < t1; t++) {
-        const int ra = 16 * t + cc;          // A[i = cc][k = h]: row ra of PSI, column 4 s + h
-        const bool oka = ra < rows;
-        const int rac = oka ? ra : rows - 1;
-        d4c_t acc = {0, 0, 0, 0};
-        UNR for (int s = 0; s < 4; s++) {
-            const double ps = PSI(rac, 4 * s + h);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(oka ? ps : 0.0, wq[s], acc, 0, 0, 0);
-        }
-        UNR for (int r = 0; r < 4; r++) {    // D[row = h + 4 r][col = cc]
-            const int row = 16 * t + h + 4 * r;
-            if (row < rows && b < d.B) AT(a.U[0], row, b) = AT(a.U0, row, b) + acc[r];
-        }
     }
 }
 
@@ -732,8 +742,7 @@ static int run_cpl(BatchCPState& st, const DevDesc& h, Bufs& bufs, const std::ve
         hipLaunchKernelGGL((k_cpl_linesearch<S, KWP>), dim3((B + 3) / 4), dim3(64), 0, stream, bufs, c);
     }
     ph(ILQR_PROF_APPLY);     // u = u0 + PSI w and the final rollout (walks the horizon)
-    hipLaunchKernelGGL((k_cpl_controls<S, KWP>), dim3((B + 15) / 16, ((T - 1) * S::NU + 255) / 256), dim3(64), 0, stream, bufs, c);
-    hipLaunchKernelGGL((k_cpl_final<S>), dim3((B + 255) / 256, DOF), dim3(256), 0, stream, bufs, c);
+    hipLaunchKernelGGL((k_cpl_final<S, KWP>), dim3((B + 255) / 256, DOF), dim3(256), 0, stream, bufs, c);
     if (hipGetLastError() != hipSuccess) { err = "ilqr_solve_batch_cp: kernel launch failed"; return 1; }
     return 0;
 }

@@ -14,7 +14,7 @@ lines = []
 CATEGORY = (("k_backward", "backward"), ("k_forward_wg", "forward"), ("k_forward_mfma", "forward"), ("k_forward_lin", "forward"),
             ("k_select", "forward"), ("k_cpl_linearize", "backward"), ("k_cp_solve", "backward"), ("k_cp_linearize", "backward"),
             ("k_cpl_linesearch", "forward"), ("k_bt_linesearch", "forward"), ("k_cpl_states", "rollout"), ("k_cpl_quad", "rollout"), ("k_cp_init", "rollout"),
-            ("k_init_", "rollout"), ("k_cpl_controls", "apply"), ("k_cpl_final", "apply"), ("k_cp_final", "apply"), ("k_apply", "apply"), ("k_blend", "apply"))
+            ("k_init_", "rollout"), ("k_cpl_final", "apply"), ("k_cp_final", "apply"), ("k_apply", "apply"), ("k_blend", "apply"))
 
 
 def category(name):
