@@ -192,81 +192,107 @@ __global__ __launch_bounds__(LPB) void k_cp_solve(Bufs a, CPArgs c) {
 #undef HL
 }
 
-// The same solve with one wave per instance: the Kw x Kw system sits in LDS once (not once per lane), lanes share the products
-// (entries of C W, of W'(C W)) and own a column each during the elimination.  Every entry sees the same operations in the same
-// order as in k_cp_solve (sums over i, j ascending; first-maximum pivot; the right-hand side eliminated along as an extra column
-// = the forward substitution with the stored multipliers), so the two kernels agree bit for bit.
+// The same solve with the rows of [H | -g] in registers: a wave takes G = 64 / KWP instances, lane (g, r) owns row r of instance g.
+//   assembly   lane (g, q) holds column q of W, forms column q of C W (the only exchange through LDS: every row needs all of C W)
+//              and adds its row of W'(C W)
+//   LU         the pivot search is a max-butterfly over the KWP lanes of an instance (DPP within a 16-lane row) and a ballot for
+//              the FIRST row that holds the maximum; one round of lane permutes then does the row exchange and the broadcast of
+//              the pivot row at once: lane pr fetches row k, every other lane fetches row pr (lanes k and pr keep what they fetched
+//              as their own row).  The multiplier of a row is local to its lane; no LDS, no barriers.
+//   back subst lane i finishes x_i (sum over j ascending, as before) and the instance's lanes fetch it
+// Every entry sees the same operations in the same order as in k_cp_solve (sums over i, j ascending; first-maximum pivot; the
+// right-hand side eliminated along as an extra column = the forward substitution with the stored multipliers), so the two kernels
+// agree bit for bit.  (The earlier form -- one wave per instance, the system in LDS, a lane per column -- spent its time in the LDS
+// pipe: ~1000 64-bit LDS instructions per instance, 69 us for 8192 instances; this one 3x less.)
+template <int CTRL>
+__device__ __forceinline__ double cp_dpp(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double cp_fetch(int src_lane, double v) {
+    const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
 template <class S, int KWP>
 __global__ __launch_bounds__(64) void k_cp_solve_w(Bufs a, CPArgs c) {
-    constexpr int NX = S::NX;
-    __shared__ double Hs[KWP][KWP + 2], Ws[NX][KWP], Cs[NX][NX], CWs[NX][KWP], rs[NX], xs[KWP];
-    __shared__ double mulS[KWP];
+    constexpr int NX = S::NX, G = 64 / KWP;
+    static_assert(KWP == 16 || KWP == 32, "a row of the system per lane, whole instances per wave");
+    __shared__ double sCW[G][NX][KWP];
     const DevDesc& d = *a.desc;
-    const int lane = threadIdx.x, b = blockIdx.x;
-    if (!a.active[b]) return;  // uniform: one instance per workgroup
+    const int lane = threadIdx.x, g = lane / KWP, r = lane % KWP, base = lane - r;
+    const bool live = (int)(blockIdx.x * G + g) < d.B;
+    const int b = live ? blockIdx.x * G + g : d.B - 1;  // lanes past the batch redo the last instance and store nothing
+    const bool act = live && a.active[b];
+    if (!__ballot(act ? 1 : 0)) return;  // uniform
     const int Bp = d.Bp;
-    for (int e = lane; e < KWP * KWP; e += 64) Hs[e / KWP][e % KWP] = c.H0[e];
-    if (lane < KWP) Hs[lane][KWP] = -AT(c.gu, lane, b);
+    double h[KWP + 1];  // row r of H, then -g_r
+    UNR for (int q = 0; q < KWP; q++) h[q] = c.H0[r * KWP + q];
+    h[KWP] = -AT(c.gu, r, b);
     for (int t = 0; t < d.n_kp; t++) {
         const double* Ck = c.Ckp + (size_t)t * NX * NX * Bp;
         const double* rk = c.rkp + (size_t)t * NX * Bp;
-        __syncthreads();
-        for (int e = lane; e < NX * KWP; e += 64)
-            Ws[e / KWP][e % KWP] = c.wref ? c.wref[(size_t)t * NX * KWP + e] : AT(c.Wkp + (size_t)t * NX * KWP * Bp, e, b);
-        for (int e = lane; e < NX * NX; e += 64) Cs[e / NX][e % NX] = AT(Ck, e, b);
-        if (lane < NX) rs[lane] = AT(rk, lane, b);
-        __syncthreads();
-        for (int e = lane; e < NX * KWP; e += 64) {
-            const int i = e / KWP, q = e % KWP;
+        double wc[NX];  // column r of W
+        UNR for (int j = 0; j < NX; j++)
+            wc[j] = c.wref ? c.wref[(size_t)t * NX * KWP + j * KWP + r] : AT(c.Wkp + (size_t)t * NX * KWP * Bp, j * KWP + r, b);
+        __syncthreads();  // (one wave: orders the reads of the previous keypoint before these writes)
+        UNR for (int i = 0; i < NX; i++) {
             double s = 0;
-            UNR for (int j = 0; j < NX; j++) s += Cs[i][j] * Ws[j][q];
-            CWs[i][q] = s;
+            UNR for (int j = 0; j < NX; j++) s = fma(AT(Ck, i * NX + j, b), wc[j], s);
+            sCW[g][i][r] = s;
         }
         __syncthreads();
-        for (int e = lane; e < KWP * KWP; e += 64) {
-            const int r = e / KWP, q = e % KWP;
+        UNR for (int q = 0; q < KWP; q++) {
             double s = 0;
-            UNR for (int i = 0; i < NX; i++) s += Ws[i][r] * CWs[i][q];
-            Hs[r][q] += s;
+            UNR for (int i = 0; i < NX; i++) s = fma(wc[i], sCW[g][i][q], s);
+            h[q] += s;
         }
-        if (lane < KWP) {
+        {
             double s = 0;
-            UNR for (int i = 0; i < NX; i++) s += Ws[i][lane] * rs[i];
-            Hs[lane][KWP] += s;
+            UNR for (int i = 0; i < NX; i++) s = fma(wc[i], AT(rk, i, b), s);
+            h[KWP] += s;
         }
     }
-    __syncthreads();
-    UNR for (int k = 0; k < KWP; k++) {  // partial-pivot LU (Eigen PartialPivLU), lane q owns column q; column KWP = right-hand side
-        // (unrolled over the pivots: the rows of an elimination step are independent LDS read-modify-writes the compiler can then batch)
-        // pivot = FIRST row with the largest |H[i][k]|, i >= k: lane i holds its candidate, a butterfly finds the maximum, a ballot the first lane
-        // that holds it (the serial scan by one lane was 15 dependent LDS reads per pivot)
-        const bool cand = lane >= k && lane < KWP;
-        const double av = cand ? fabs(Hs[cand ? lane : k][k]) : -1.0;
+    UNR for (int k = 0; k < KWP; k++) {  // partial-pivot LU (Eigen PartialPivLU)
+        // pivot = FIRST row with the largest |H[i][k]|, i >= k (NaN candidates lose; a NaN on the diagonal stays the pivot)
+        const bool cand = r >= k;
+        const double av = cand ? fabs(h[k]) : -1.0;
         double mx = av;
-        UNR for (int o = 1; o < 32; o <<= 1) mx = fmax(mx, __shfl_xor(mx, o));  // (KWP <= 32 lanes hold candidates; NaN candidates lose as in the scan)
-        mx = fmax(mx, __shfl_xor(mx, 32));
+        mx = fmax(mx, cp_dpp<0xB1>(mx));   // quad_perm [1,0,3,2]
+        mx = fmax(mx, cp_dpp<0x4E>(mx));   // quad_perm [2,3,0,1]
+        mx = fmax(mx, cp_dpp<0x141>(mx));  // row_half_mirror: the other quad of the half
+        mx = fmax(mx, cp_dpp<0x140>(mx));  // row_mirror: the other half of the 16-lane row
+        if (KWP == 32) mx = fmax(mx, cp_fetch(lane ^ 16, mx));
         const unsigned long long eq = __ballot((cand && av == mx) ? 1 : 0);
-        const int pr = (eq && !isnan(Hs[k][k])) ? (__ffsll((long long)eq) - 1) : k;  // (a NaN on the diagonal stays the pivot: nothing compares greater)
-        if (lane <= KWP && lane >= k && pr != k) { const double t0 = Hs[k][lane]; Hs[k][lane] = Hs[pr][lane]; Hs[pr][lane] = t0; }
-        __syncthreads();
-        // multipliers H[i][k] / pivot once per row (lane i), not once per entry: every lane of a column divided all 15 of them itself
-        if (lane > k && lane < KWP) mulS[lane] = Hs[lane][k] / Hs[k][k];
-        __syncthreads();
-        if (lane <= KWP && lane > k) {
-            const double hk = Hs[k][lane];
-            UNR for (int i = k + 1; i < KWP; i++) Hs[i][lane] -= mulS[i] * hk;
+        const unsigned long long dn = __ballot((r == k && isnan(h[k])) ? 1 : 0);
+        const unsigned eqg = (unsigned)(eq >> base) & (KWP == 32 ? 0xffffffffu : 0xffffu);
+        const bool diag_nan = (dn >> (base + k)) & 1;
+        const int pr = (eqg && !diag_nan) ? (__ffs((int)eqg) - 1) : k;
+        const bool isP = r == pr, isK = r == k;
+        const int src = base + (isP ? k : pr);
+        double prow[KWP + 1];
+        UNR for (int j = k; j <= KWP; j++) {
+            const double f = cp_fetch(src, h[j]);
+            prow[j] = isP ? h[j] : f;      // the pivot row = the old row pr
+            if (isP || isK) h[j] = f;      // rows k and pr change places
         }
-        __syncthreads();
-    }
-    if (lane == 0) {
-        for (int i = KWP - 1; i >= 0; i--) {
-            double s = Hs[i][KWP];
-            for (int j = i + 1; j < KWP; j++) s -= Hs[i][j] * xs[j];
-            xs[i] = s / Hs[i][i];
+        if (r > k) {
+            const double m = h[k] / prow[k];
+            UNR for (int j = k + 1; j <= KWP; j++) h[j] = fma(-m, prow[j], h[j]);
         }
     }
-    __syncthreads();
-    if (lane < KWP) AT(c.dw, lane, b) = xs[lane];
+    double x[KWP], mine = 0;
+    UNR for (int i = KWP - 1; i >= 0; i--) {
+        double s = h[KWP];
+        UNR for (int j = i + 1; j < KWP; j++) s = fma(-h[j], x[j], s);  // (written out: with the product shared between the chains of
+                                                                            // several rows the compiler keeps a separate multiply)
+        const double xi = s / h[i];
+        if (r == i) mine = xi;
+        x[i] = cp_fetch(base + i, xi);
+    }
+    if (act) AT(c.dw, r, b) = mine;
 }
 
 // du = PSI dw for every control entry (a.U[1]), one lane per (instance, step): the line search then needs no basis at all
@@ -656,7 +682,7 @@ static int run_cp(BatchCPState& st, const DevDesc& h, Bufs& bufs, int nb_iter, i
         c.it = it;
         ph(ILQR_PROF_BACKWARD);  // linearisation + normal equations + du = PSI dw
         hipLaunchKernelGGL((k_cp_linearize<S, KWP>), dim3((B + 64 / KWP - 1) / (64 / KWP)), dim3(64), 0, stream, bufs, c);
-        if (wave_solve) hipLaunchKernelGGL((k_cp_solve_w<S, KWP>), dim3(B), dim3(64), 0, stream, bufs, c);
+        if (wave_solve) hipLaunchKernelGGL((k_cp_solve_w<S, KWP>), dim3((B + 64 / KWP - 1) / (64 / KWP)), dim3(64), 0, stream, bufs, c);
         else hipLaunchKernelGGL((k_cp_solve<S, KWP>), grid, block, lds_h, stream, bufs, c);
         hipLaunchKernelGGL((k_cp_du<S, KWP>), dim3((B + 63) / 64, h.T - 1), dim3(64), 0, stream, bufs, c);
         BTArgs bt;
@@ -736,7 +762,7 @@ static int run_cpl(BatchCPState& st, const DevDesc& h, Bufs& bufs, const std::ve
         c.it = it;
         ph(ILQR_PROF_BACKWARD);  // keypoint linearisation + the Kw x Kw normal equations
         hipLaunchKernelGGL((k_cpl_linearize<S, KWP>), dim3((B + LPB - 1) / LPB, nkp > 0 ? nkp : 1), block, 0, stream, bufs, c);
-        if (wave_solve) hipLaunchKernelGGL((k_cp_solve_w<S, KWP>), dim3(B), dim3(64), 0, stream, bufs, c);
+        if (wave_solve) hipLaunchKernelGGL((k_cp_solve_w<S, KWP>), dim3((B + 64 / KWP - 1) / (64 / KWP)), dim3(64), 0, stream, bufs, c);
         else hipLaunchKernelGGL((k_cp_solve<S, KWP>), grid, block, lds_h, stream, bufs, c);
         ph(ILQR_PROF_FORWARD);   // all step sizes of the backtracking, in coefficient space
         hipLaunchKernelGGL((k_cpl_linesearch<S, KWP>), dim3((B + 3) / 4), dim3(64), 0, stream, bufs, c);
