@@ -455,33 +455,35 @@ __global__ __launch_bounds__(LPB) void k_cpl_linearize(Bufs a, CPArgs c) {
     }
 }
 
-// Backtracking with all step sizes at once: 16 lanes per instance, lane l tries alpha = 2^-l (l = 0 .. 10; the reference's loop
-// stops at the first alpha whose cost improves or at alpha < 1e-3, BatchILQRCP.cpp:138-158 -- the first such lane wins).  The chain a
-// lane walks is one cost evaluation instead of up to eleven.
-template <class S, int KWP>
+// Backtracking with several step sizes at once, in two passes: lane l of an instance tries alpha = 2^-l (the reference's loop stops at the
+// first alpha whose cost improves or at alpha < 1e-3, BatchILQRCP.cpp:138-158 -- the first such lane wins), so the chain a lane walks
+// is one cost evaluation instead of up to eleven.
+//   pass 1 (LPI = 4, L0 = 0)   alpha = 1 .. 1/8, 16 instances per wave: 99.3 % of the C5 line searches end here (profiles/r02_batch_scan.txt)
+//   pass 2 (LPI = 8, L0 = 4)   alpha = 1/16 .. 2^-10 for the instances pass 1 left without a winner (iters[b] still at the old count);
+//                              waves without such an instance leave after two loads
+// (One pass with 16 lanes per instance -- all eleven step sizes -- evaluated 16 costs per instance where 1.7 are needed on average: 72 us
+// per launch against 42 + 24 us for the two passes.  What a pass waits for is the chain of ONE cost evaluation, ~20 us with a wave per SIMD;
+// sharing the keypoints of an evaluation between two lanes was tried and did not shorten it: 41 + 22 us, at 512 VGPRs with spills.)
+template <class S, int KWP, int LPI, int L0>
 __global__ __launch_bounds__(64) void k_cpl_linesearch(Bufs a, CPArgs c) {
     const DevDesc& d = *a.desc;
-    const int lane = threadIdx.x, l = lane & 15, bq = blockIdx.x * 4 + (lane >> 4);
-    const bool ok = bq < d.B && a.active[bq < d.B ? bq : 0];
+    const int lane = threadIdx.x, l = L0 + (lane & (LPI - 1)), bq = blockIdx.x * (64 / LPI) + lane / LPI;
+    bool ok = bq < d.B && a.active[bq < d.B ? bq : 0];
+    if (L0 > 0) ok = ok && a.iters[bq < d.B ? bq : 0] != c.it + 1;  // pass 2: only what pass 1 left undecided
+    if (!__ballot(ok ? 1 : 0)) return;
     const int b = ok ? bq : 0;
     const int Bp = d.Bp;
     double w[KWP], dw[KWP], g0[KWP], wn[KWP];
     UNR for (int q = 0; q < KWP; q++) { w[q] = AT(c.wv, q, b); dw[q] = AT(c.dw, q, b); g0[q] = AT(c.g0, q, b); }
-    double dun2 = 0;  // sum_k ||PSI_k dw||^2
-    UNR for (int q = 0; q < KWP; q++) {
-        double s = 0;
-        UNR for (int r = 0; r < KWP; r++) s += c.pp[q * KWP + r] * dw[r];
-        dun2 += dw[q] * s;
-    }
     const double cost0 = a.cost[b], c00 = c.c00[b];
     const double alpha = ldexp(1.0, -(l < 11 ? l : 10));
     UNR for (int q = 0; q < KWP; q++) wn[q] = w[q] + alpha * dw[q];
     const double cost = cpl_cost<S, KWP>(d, a, c, b, wn, g0, c00);
     const bool take = (l < 11) && ((cost < cost0) || (alpha < 1e-3));
     const unsigned long long m = __ballot(take ? 1 : 0);
-    const unsigned grp = (unsigned)((m >> (lane & 48)) & 0xffffull);  // this instance's 16 lanes; lane 10 always votes
-    const int win = __ffs(grp) - 1;
-    if (!ok || l != win) return;
+    const unsigned grp = (unsigned)((m >> (lane & ~(LPI - 1))) & ((1u << LPI) - 1));  // this instance's lanes; lane l = 10 always votes
+    const int win = L0 + __ffs(grp) - 1;
+    if (!ok || !grp || l != win) return;
     UNR for (int q = 0; q < KWP; q++) AT(c.wv, q, b) = wn[q];
     a.alpha[b] = alpha;
     a.iters[b] = c.it + 1;
@@ -491,7 +493,15 @@ __global__ __launch_bounds__(64) void k_cpl_linesearch(Bufs a, CPArgs c) {
         a.alpha_trace[(size_t)c.it * Bp + b] = alpha;
     }
     a.cost[b] = cost;
-    if (c.early_stop && alpha * sqrt(dun2 > 0 ? dun2 : 0.0) < 1e-3) a.active[b] = 0;  // :167
+    if (c.early_stop) {
+        double dun2 = 0;  // sum_k ||PSI_k dw||^2
+        UNR for (int q = 0; q < KWP; q++) {
+            double s = 0;
+            UNR for (int r = 0; r < KWP; r++) s += c.pp[q * KWP + r] * dw[r];
+            dun2 += dw[q] * s;
+        }
+        if (alpha * sqrt(dun2 > 0 ? dun2 : 0.0) < 1e-3) a.active[b] = 0;  // :167
+    }
 }
 
 // ---- the horizon walks of the coefficient-space path with one lane per (instance, coordinate) / per (instance, chunk of steps).
@@ -765,7 +775,8 @@ static int run_cpl(BatchCPState& st, const DevDesc& h, Bufs& bufs, const std::ve
         if (wave_solve) hipLaunchKernelGGL((k_cp_solve_w<S, KWP>), dim3((B + 64 / KWP - 1) / (64 / KWP)), dim3(64), 0, stream, bufs, c);
         else hipLaunchKernelGGL((k_cp_solve<S, KWP>), grid, block, lds_h, stream, bufs, c);
         ph(ILQR_PROF_FORWARD);   // all step sizes of the backtracking, in coefficient space
-        hipLaunchKernelGGL((k_cpl_linesearch<S, KWP>), dim3((B + 3) / 4), dim3(64), 0, stream, bufs, c);
+        hipLaunchKernelGGL((k_cpl_linesearch<S, KWP, 4, 0>), dim3((B + 15) / 16), dim3(64), 0, stream, bufs, c);
+        hipLaunchKernelGGL((k_cpl_linesearch<S, KWP, 8, 4>), dim3((B + 7) / 8), dim3(64), 0, stream, bufs, c);
     }
     ph(ILQR_PROF_APPLY);     // u = u0 + PSI w and the final rollout (walks the horizon)
     hipLaunchKernelGGL((k_cpl_final<S, KWP>), dim3((B + 255) / 256, DOF), dim3(256), 0, stream, bufs, c);

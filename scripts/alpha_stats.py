@@ -9,10 +9,11 @@ cfg = workloads.config(name)
 B = 4096
 desc, inp = workloads.make_batch(ctx, cfg, B=B)
 p = workloads.load_batch(ctx, desc, inp, B)
-n = workloads.run_solver(p, cfg, early_stop=False)
+psi = workloads.psi_of(cfg['psi'], p.T, p.dims.n_u) if cfg['solver'] == 'batch_cp' else None
+n = workloads.run_solver(p, cfg, early_stop=False, psi=psi)
 ct, at = p.trace(n)
 idx = np.round(-np.log2(at)).astype(int)
-print("mean trials", (idx + 1).mean())
+print("mean trials", (idx + 1).mean(), " winner histogram", np.bincount(idx.reshape(-1), minlength=11) / idx.size)
 for it in range(n):
     prev = idx[:, it - 1] if it > 0 else np.zeros(B, int)
     mis = (idx[:, it] != prev)
