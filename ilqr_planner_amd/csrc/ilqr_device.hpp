@@ -251,8 +251,10 @@ ILQR_DEV void fx_of(const DevDesc& d, const double* x, double* fxv, double (*J)[
         return;
     }
     double Jl[6][DOF];
-    double (*Jp)[DOF] = (WANT_J || S::ND == 2) ? (WANT_J ? J : Jl) : nullptr;
-    if (WANT_J || S::ND == 2) fk<true>(d.chain, x, fxv, fxv + 3, Jp);
+    double (*Jp)[DOF] = nullptr;
+    if constexpr (WANT_J) Jp = J;
+    else if constexpr (S::ND == 2) Jp = Jl;
+    if constexpr (WANT_J || S::ND == 2) fk<true>(d.chain, x, fxv, fxv + 3, Jp);
     else fk<false>(d.chain, x, fxv, fxv + 3, nullptr);
     if (kpi >= 0 && d.kp_frame[kpi]) {  // TransformedSimulationInterface.cpp:53-103
         const double* R = d.kp_fR[kpi];
@@ -277,7 +279,7 @@ ILQR_DEV void fx_of(const DevDesc& d, const double* x, double* fxv, double (*J)[
         eig_mat_to_quat(mm, fxv + 3);
 #pragma unroll
         for (int i = 0; i < 3; i++) fxv[i] = pp[i];
-        if (Jp) {
+        if constexpr (WANT_J || S::ND == 2) {  // (not `if (Jp)`: the null test of a private pointer is not folded and keeps the array in scratch)
 #pragma unroll
             for (int blk = 0; blk < 2; blk++)
 #pragma unroll
