@@ -196,14 +196,13 @@ __global__ __launch_bounds__(LPB) void k_cp_solve(Bufs a, CPArgs c) {
 //   assembly   lane (g, q) holds column q of W, forms column q of C W (the only exchange through LDS: every row needs all of C W)
 //              and adds its row of W'(C W)
 //   LU         the pivot search is a max-butterfly over the KWP lanes of an instance (DPP within a 16-lane row) and a ballot for
-//              the FIRST row that holds the maximum; one round of lane permutes then does the row exchange and the broadcast of
-//              the pivot row at once: lane pr fetches row k, every other lane fetches row pr (lanes k and pr keep what they fetched
-//              as their own row).  The multiplier of a row is local to its lane; no LDS, no barriers.
+//              the FIRST row that holds the maximum; a round of lane permutes exchanges rows k and pr, a second one hands the
+//              pivot row (now in lane k) to every lane.  The multiplier of a row is local to its lane; no LDS, no barriers.
 //   back subst lane i finishes x_i (sum over j ascending, as before) and the instance's lanes fetch it
 // Every entry sees the same operations in the same order as in k_cp_solve (sums over i, j ascending; first-maximum pivot; the
 // right-hand side eliminated along as an extra column = the forward substitution with the stored multipliers), so the two kernels
 // agree bit for bit.  (The earlier form -- one wave per instance, the system in LDS, a lane per column -- spent its time in the LDS
-// pipe: ~1000 64-bit LDS instructions per instance, 69 us for 8192 instances; this one 3x less.)
+// pipe: ~1000 64-bit LDS instructions per instance, 69 us for 8192 instances; this one 30 us, 14 of them the assembly.)
 template <int CTRL>
 __device__ __forceinline__ double cp_dpp(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -221,6 +220,7 @@ __global__ __launch_bounds__(64) void k_cp_solve_w(Bufs a, CPArgs c) {
     constexpr int NX = S::NX, G = 64 / KWP;
     static_assert(KWP == 16 || KWP == 32, "a row of the system per lane, whole instances per wave");
     __shared__ double sCW[G][NX][KWP];
+    __shared__ __attribute__((aligned(16))) double sC[G][(NX * NX + 1) & ~1];
     const DevDesc& d = *a.desc;
     const int lane = threadIdx.x, g = lane / KWP, r = lane % KWP, base = lane - r;
     const bool live = (int)(blockIdx.x * G + g) < d.B;
@@ -238,9 +238,13 @@ __global__ __launch_bounds__(64) void k_cp_solve_w(Bufs a, CPArgs c) {
         UNR for (int j = 0; j < NX; j++)
             wc[j] = c.wref ? c.wref[(size_t)t * NX * KWP + j * KWP + r] : AT(c.Wkp + (size_t)t * NX * KWP * Bp, j * KWP + r, b);
         __syncthreads();  // (one wave: orders the reads of the previous keypoint before these writes)
+        // C of the instance goes through LDS: every lane of the instance needs all of it, and as loads that is NX^2 vector-memory
+        // instructions per lane with one useful address per 16 lanes (the address unit, not the data, was the cost: 49 loads -> 4)
+        for (int e = r; e < NX * NX; e += KWP) sC[g][e] = AT(Ck, e, b);
+        __syncthreads();
         UNR for (int i = 0; i < NX; i++) {
             double s = 0;
-            UNR for (int j = 0; j < NX; j++) s = fma(AT(Ck, i * NX + j, b), wc[j], s);
+            UNR for (int j = 0; j < NX; j++) s = fma(sC[g][i * NX + j], wc[j], s);
             sCW[g][i][r] = s;
         }
         __syncthreads();
@@ -270,14 +274,13 @@ __global__ __launch_bounds__(64) void k_cp_solve_w(Bufs a, CPArgs c) {
         const unsigned eqg = (unsigned)(eq >> base) & (KWP == 32 ? 0xffffffffu : 0xffffu);
         const bool diag_nan = (dn >> (base + k)) & 1;
         const int pr = (eqg && !diag_nan) ? (__ffs((int)eqg) - 1) : k;
-        const bool isP = r == pr, isK = r == k;
-        const int src = base + (isP ? k : pr);
+        // two rounds of lane permutes and no selects: rows k and pr change places (the other lanes fetch themselves), then every lane
+        // fetches the pivot row from lane k.  (One round -- lane pr fetches row k, the others row pr -- needs a select per register
+        // between fetched and own values afterwards, and those selects cost more than the second round: 45 us against 30.)
+        const int src = base + ((r == pr) ? k : ((r == k) ? pr : r));
         double prow[KWP + 1];
-        UNR for (int j = k; j <= KWP; j++) {
-            const double f = cp_fetch(src, h[j]);
-            prow[j] = isP ? h[j] : f;      // the pivot row = the old row pr
-            if (isP || isK) h[j] = f;      // rows k and pr change places
-        }
+        UNR for (int j = k; j <= KWP; j++) h[j] = cp_fetch(src, h[j]);
+        UNR for (int j = k; j <= KWP; j++) prow[j] = cp_fetch(base + k, h[j]);
         if (r > k) {
             const double m = h[k] / prow[k];
             UNR for (int j = k + 1; j <= KWP; j++) h[j] = fma(-m, prow[j], h[j]);
