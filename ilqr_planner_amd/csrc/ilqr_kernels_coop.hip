@@ -60,6 +60,9 @@ __global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a, SweepArgs sw) {
     __shared__ __attribute__((aligned(16))) double sA[IPW][N][10];  // symmetric matrix, full storage; rows padded to 80 B: row starts fall
                                                                      // in distinct banks (20 i mod 64) and stay 16-B aligned for ds_read_b128
     __shared__ double sV[IPW][3][8];   // 0: x   1: Qu   2: dv
+    // gain records of the wave's instances as they lie in memory (IPW records of RS doubles, adjacent): the lanes write their entries here
+    // and the record goes out as 16-byte pieces of whole lines -- one store per step instead of three 8-byte ones (K_ij, K_ji, d)
+    __shared__ __attribute__((aligned(16))) double sK[IPW][RS];
     const DevDesc& d = *a.desc;
     const int lane = threadIdx.x, g = lane / LPI, l = lane % LPI;
     const int b = xcd_tile() * IPW + g;
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a, SweepArgs sw) {
     int lw_i[EPL];
     double *sAij[EPL], *sAji[EPL];
     const double *rowI[EPL], *rowJ[EPL];
-    double *Kij[EPL], *Kji[EPL];
+    double *Kij[EPL], *Kji[EPL];  // entries (i, j) and (j, i) of the gain record image in LDS
     UNR for (int e = 0; e < EPL; e++) {
         const int n = l + e * LPI;
         isE[e] = n < 28;
@@ -114,8 +117,8 @@ __global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a, SweepArgs sw) {
         smax_i[e] = we ? d.smax[i] : __builtin_inf(); smin_i[e] = we ? d.smin[i] : -__builtin_inf();
         sAij[e] = &sA[g][i][j]; sAji[e] = &sA[g][j][i];
         rowI[e] = &sA[g][i][0]; rowJ[e] = &sA[g][j][0];
-        Kij[e] = KD_REC(a.KD, Bp, RS, T - 2, bb) + i * ROWP + j;
-        Kji[e] = KD_REC(a.KD, Bp, RS, T - 2, bb) + j * ROWP + i;
+        Kij[e] = &sK[g][i * ROWP + j];
+        Kji[e] = &sK[g][j * ROWP + i];
     }
     const double* rowV = &sA[g][v][0];
     // sweep operands per pivot c: a_ic, a_jc from the lower triangle (rows are padded: column 9 of row 0 holds the constant -1 the entries
@@ -148,7 +151,16 @@ __global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a, SweepArgs sw) {
     }
     // running pointers (decremented by one timestep per iteration: no 64-bit multiplies in the loop)
     const ptrdiff_t Kstep = (ptrdiff_t)Bp * RS, Vstep = (ptrdiff_t)N * Bp, Lstep = (ptrdiff_t)m * Bp;
-    double* Dv_out = KD_REC(a.KD, Bp, RS, T - 2, bb) + v * ROWP + N;
+    double* Dv_out = &sK[g][v * ROWP + N];
+    // lane c < IPW * RS / 2 stores piece c of the image: piece c belongs to instance c / (RS / 2) of the wave
+    constexpr int PCS = RS / 2;
+    static_assert(RS % 2 == 0 && IPW * PCS <= 64, "one 16-byte piece per lane");
+    const int gc = (lane / PCS < IPW) ? lane / PCS : 0, cc = lane % PCS;
+    const unsigned long long okm = __ballot(ok ? 1 : 0);
+    const bool okc = lane < IPW * PCS && ((okm >> (gc * LPI)) & 1ull);
+    const int bc = xcd_tile() * IPW + gc;
+    double* Kout = KD_REC(a.KD, Bp, RS, T - 2, (bc < d.B) ? bc : 0) + cc * 2;
+    const double* Kimg = &sK[gc][cc * 2];
 
     int kpi = d.n_kp - 1;
     int kp_next = (kpi >= 0) ? d.kp_t[kpi] : -1;
@@ -299,15 +311,18 @@ __global__ __launch_bounds__(64) void k_backward_si_coop(Bufs a, SweepArgs sw) {
         }
         // ---- gains out
         UNR for (int e = 0; e < EPL; e++) {
-            if (ok && isE[e]) {
+            if (isE[e]) {
                 *Kij[e] = (M[e] * Dj[e] - del[e]) * idt;
                 if (!dg[e]) *Kji[e] = (M[e] * Di[e]) * idt;
             }
-            Kij[e] -= Kstep;
-            Kji[e] -= Kstep;
         }
-        if (ok && isV) *Dv_out = dv;
-        Dv_out -= Kstep;
+        if (isV) *Dv_out = dv;
+        LDS_ORDER();
+        if (okc) {
+            const double k0v = Kimg[0], k1v = Kimg[1];
+            Kout[0] = k0v; Kout[1] = k1v;
+        }
+        Kout -= Kstep;
         // ---- stage derivatives l_xx (entries), l_x (vector component)
         double lxx[EPL], lx = 0;
         UNR for (int e = 0; e < EPL; e++) lxx[e] = 0;
