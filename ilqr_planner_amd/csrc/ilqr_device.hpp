@@ -167,14 +167,13 @@ template <bool WANT_J>
 ILQR_DEV void fk(const DevChain& c, const double* q, double p[3], double quat[4], double (*J)[DOF]) {
     double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pos[3] = {0, 0, 0};
     double org[DOF][3], ax[DOF][3];
-#pragma unroll
-    for (int j = 0; j < DOF; j++) {
+    auto joint = [&](const int j, const double qj) {
         double Rn[9];
 #pragma unroll
         for (int i = 0; i < 3; i++) pos[i] += R[3 * i] * c.ppre[j][0] + R[3 * i + 1] * c.ppre[j][1] + R[3 * i + 2] * c.ppre[j][2];
         mat3_mul(R, c.Rpre[j], Rn);
         const double x = c.axis[j][0], y = c.axis[j][1], z = c.axis[j][2];
-        if (WANT_J) {
+        if constexpr (WANT_J) {
 #pragma unroll
             for (int i = 0; i < 3; i++) {
                 org[j][i] = pos[i];
@@ -182,12 +181,28 @@ ILQR_DEV void fk(const DevChain& c, const double* q, double p[3], double quat[4]
             }
         }
         double st, ct;
-        sincos(q[j], &st, &ct);
+        sincos(qj, &st, &ct);
         double vt = 1 - ct;
         double Rq[9] = {ct + vt * x * x,      -z * st + vt * x * y, y * st + vt * x * z,
                         z * st + vt * x * y,  ct + vt * y * y,      -x * st + vt * y * z,
                         -y * st + vt * x * z, x * st + vt * y * z,  ct + vt * z * z};
         mat3_mul(Rn, Rq, R);
+    };
+    if constexpr (WANT_J) {  // the Jacobian keeps every joint's origin and axis: static indices, so the joints are unrolled
+#pragma unroll
+        for (int j = 0; j < DOF; j++) joint(j, q[j]);
+    } else {
+        // Pose only: ONE copy of the joint step (sincos + two rotation products, ~400 instructions) in a rolled loop instead of seven.  The
+        // kernels that hold this code are short launches between the streaming kernels of an iteration: they start with the instruction
+        // cache and the L2 cold, and fetching their code -- not executing it -- set their time.  The joint angle is picked
+        // by selects (q[] stays in registers); the chain constants are uniform loads.  Same operations in the same order: same bits.
+#pragma unroll 1
+        for (int j = 0; j < DOF; j++) {
+            double qj = q[0];
+#pragma unroll
+            for (int i = 1; i < DOF; i++) qj = (j == i) ? q[i] : qj;
+            joint(j, qj);
+        }
     }
     {
         double Rn[9];

@@ -260,12 +260,17 @@ __global__ __launch_bounds__(FW_IW * 32) void k_forward_wg(Bufs a, FwdArgs f) {
 // steps + the limit cost k_forward_w32 accumulated; the first alpha (descending) whose cost is below the current one wins, else
 // the last one tried (ILQRRecursive.cpp:101-155).  Writes cost/alpha/iters/status/traces, `pend` for k_blend/k_flip, and the
 // early-stop flag.
-template <class S, int NA, bool EXT>
-__global__ __launch_bounds__(64) void k_select(Bufs a, FwdArgs f) {
+// KW = 2: the keypoints are dealt to the two waves of the workgroup (keypoint kpi to wave kpi mod 2) -- the kernel is one chain of dependent
+// instructions per keypoint (FK: seven sincos and rotation products) on 1024 waves, one per SIMD, so a second wave per SIMD hides half of
+// it.  The per-keypoint costs meet in LDS and wave 0 adds them in keypoint order: the bits of the one-wave sum.
+template <class S, int NA, bool EXT, int KW>
+__global__ __launch_bounds__(64 * KW) void k_select(Bufs a, FwdArgs f) {
     constexpr int NX = S::NX, NU = S::NU;
     static_assert(NA <= 16, "16 lanes per instance");
+    static_assert(KW == 1 || KW == 2, "one or two waves per four instances");
+    __shared__ double sc[KW == 2 ? MAX_KP : 1][64];
     const DevDesc& d = *a.desc;
-    const int lane = threadIdx.x, gi = lane >> 4, al = lane & 15;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, gi = lane >> 4, al = lane & 15;
     const int b = blockIdx.x * 4 + gi;
     const int Bp = d.Bp, T = d.T, B = d.B;
     const bool inst_ok = (b < B) && (a.active[b < B ? b : 0] != 0);
@@ -277,17 +282,24 @@ __global__ __launch_bounds__(64) void k_select(Bufs a, FwdArgs f) {
     if (mine) {
         const double* Xb = a.X[a.cur[bb]];
         const double* Ub = a.U[a.cur[bb]];
-        for (int kpi = 0; kpi < d.n_kp; kpi++) {
+        for (int kpi = wv; kpi < d.n_kp; kpi += KW) {
             const int k = d.kp_t[kpi];
             const double* dv = a.kpdev + (size_t)kpi * (NX + NU) * Bp;
             double xt[NX], ut[NU], tg[S::NF];
             UNR for (int i = 0; i < NX; i++) xt[i] = fma(aa, AT(dv, i, bb), AT(Xb, k * NX + i, bb));
             UNR for (int i = 0; i < NU; i++) ut[i] = (k < T - 1) ? fma(aa, AT(dv, NX + i, bb), AT(Ub, k * NU + i, bb)) : 0.0;
             UNR for (int i = 0; i < S::NF; i++) tg[i] = AT(a.kp_tg, kpi * S::NF + i, bb);
-            c += kp_cost<S, EXT>(d, kpi, tg, xt, ut);
+            const double ck = kp_cost<S, EXT>(d, kpi, tg, xt, ut);
+            if (KW == 1) c += ck;
+            else sc[kpi][lane] = ck;
         }
-        c += AT(a.lsc, al, bb);
     }
+    if (KW == 2) {
+        __syncthreads();
+        if (wv != 0) return;
+        if (mine) { for (int kpi = 0; kpi < d.n_kp; kpi++) c += sc[kpi][lane]; }
+    }
+    if (mine) c += AT(a.lsc, al, bb);
     const double cost0 = a.cost[bb];
     const bool okc = mine && !((c >= cost0) || isnan(c));
     const unsigned m16 = (unsigned)((__ballot(okc ? 1 : 0) >> (gi * 16)) & 0xffffull);
@@ -493,9 +505,14 @@ void launch_apply_wave(int kind, const Bufs& a, int B, int T, hipStream_t st, co
 
 template <class S, int NA>
 static void launch_select(const Bufs& a, int B, hipStream_t st, const FwdArgs& f) {
-    const dim3 sgrid((B + 3) / 4), sblock(64);
-    if (f.kp_ext) hipLaunchKernelGGL((k_select<S, NA, true>), sgrid, sblock, 0, st, a, f);
-    else hipLaunchKernelGGL((k_select<S, NA, false>), sgrid, sblock, 0, st, a, f);
+    const dim3 sgrid((B + 3) / 4);
+    if (f.n_kp >= 2) {  // two waves share the keypoints of four instances
+        if (f.kp_ext) hipLaunchKernelGGL((k_select<S, NA, true, 2>), sgrid, dim3(128), 0, st, a, f);
+        else hipLaunchKernelGGL((k_select<S, NA, false, 2>), sgrid, dim3(128), 0, st, a, f);
+    } else {
+        if (f.kp_ext) hipLaunchKernelGGL((k_select<S, NA, true, 1>), sgrid, dim3(64), 0, st, a, f);
+        else hipLaunchKernelGGL((k_select<S, NA, false, 1>), sgrid, dim3(64), 0, st, a, f);
+    }
 }
 // the rollout itself knows no keypoint function (single-integrator dynamics); the decision kernel is per system kind
 template <class S>
