@@ -163,8 +163,10 @@ ILQR_DEV void kdl_quat(const double* R, double q[4]) {
 }
 
 // p, quat and (optionally) the 6x7 geometric Jacobian, columns [z_j x (p - o_j); z_j] in the base frame.
-template <bool WANT_J>
-ILQR_DEV void fk(const DevChain& c, const double* q, double p[3], double quat[4], double (*J)[DOF]) {
+// ROLL (with WANT_J): the joints' origins and axes go to `lj` -- wave-private LDS, entry e of this lane at lj[e * 64] -- instead of
+// register arrays, so that the joint loop can stay rolled (see below); the Jacobian is formed from there with static indices.
+template <bool WANT_J, bool ROLL = false>
+ILQR_DEV void fk(const DevChain& c, const double* q, double p[3], double quat[4], double (*J)[DOF], double* lj = nullptr) {
     double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pos[3] = {0, 0, 0};
     double org[DOF][3], ax[DOF][3];
     auto joint = [&](const int j, const double qj) {
@@ -176,8 +178,9 @@ ILQR_DEV void fk(const DevChain& c, const double* q, double p[3], double quat[4]
         if constexpr (WANT_J) {
 #pragma unroll
             for (int i = 0; i < 3; i++) {
-                org[j][i] = pos[i];
-                ax[j][i] = Rn[3 * i] * x + Rn[3 * i + 1] * y + Rn[3 * i + 2] * z;
+                const double axi = Rn[3 * i] * x + Rn[3 * i + 1] * y + Rn[3 * i + 2] * z;
+                if constexpr (ROLL) { lj[(j * 6 + i) * 64] = pos[i]; lj[(j * 6 + 3 + i) * 64] = axi; }
+                else { org[j][i] = pos[i]; ax[j][i] = axi; }
             }
         }
         double st, ct;
@@ -188,7 +191,7 @@ ILQR_DEV void fk(const DevChain& c, const double* q, double p[3], double quat[4]
                         -y * st + vt * x * z, x * st + vt * y * z,  ct + vt * z * z};
         mat3_mul(Rn, Rq, R);
     };
-    if constexpr (WANT_J) {  // the Jacobian keeps every joint's origin and axis: static indices, so the joints are unrolled
+    if constexpr (WANT_J && !ROLL) {  // the Jacobian keeps every joint's origin and axis: static indices, so the joints are unrolled
 #pragma unroll
         for (int j = 0; j < DOF; j++) joint(j, q[j]);
     } else {
@@ -196,11 +199,20 @@ ILQR_DEV void fk(const DevChain& c, const double* q, double p[3], double quat[4]
         // kernels that hold this code are short launches between the streaming kernels of an iteration: they start with the instruction
         // cache and the L2 cold, and fetching their code -- not executing it -- set their time.  The joint angle is picked
         // by selects (q[] stays in registers); the chain constants are uniform loads.  Same operations in the same order: same bits.
+        if constexpr (ROLL) {  // (with the Jacobian's register pressure the select chain became an indexed stack object: the angles go through LDS too)
+#pragma unroll
+            for (int i = 0; i < DOF; i++) lj[(6 * DOF + i) * 64] = q[i];
+        }
 #pragma unroll 1
         for (int j = 0; j < DOF; j++) {
-            double qj = q[0];
+            double qj;
+            if constexpr (ROLL) {
+                qj = lj[(6 * DOF + j) * 64];
+            } else {
+                qj = q[0];
 #pragma unroll
-            for (int i = 1; i < DOF; i++) qj = (j == i) ? q[i] : qj;
+                for (int i = 1; i < DOF; i++) qj = (j == i) ? q[i] : qj;
+            }
             joint(j, qj);
         }
     }
@@ -213,6 +225,12 @@ ILQR_DEV void fk(const DevChain& c, const double* q, double p[3], double quat[4]
     }
     p[0] = pos[0]; p[1] = pos[1]; p[2] = pos[2];
     if (WANT_J) {
+        if constexpr (ROLL) {
+#pragma unroll
+            for (int j = 0; j < DOF; j++)
+#pragma unroll
+                for (int i = 0; i < 3; i++) { org[j][i] = lj[(j * 6 + i) * 64]; ax[j][i] = lj[(j * 6 + 3 + i) * 64]; }
+        }
 #pragma unroll
         for (int j = 0; j < DOF; j++) {
             double r0 = pos[0] - org[j][0], r1 = pos[1] - org[j][1], r2 = pos[2] - org[j][2];
@@ -258,8 +276,8 @@ ILQR_DEV void eig_mat_to_quat(const double* m, double* q) {
 }
 
 // f(x) of getFxJac: [p; quat (; dp; dquat) (; t)]  and the 6x7 Jacobian block (the full J is blkdiag(J,J) bordered by 1)
-template <class S, bool WANT_J>
-ILQR_DEV void fx_of(const DevDesc& d, const double* x, double* fxv, double (*J)[DOF], int kpi = -1) {
+template <class S, bool WANT_J, bool ROLL = false>
+ILQR_DEV void fx_of(const DevDesc& d, const double* x, double* fxv, double (*J)[DOF], int kpi = -1, double* lj = nullptr) {
     if (S::JOINT) {  // JointSpacePlannerSys::getFxJac: f(x) = x (J = I is applied by the callers)
 #pragma unroll
         for (int i = 0; i < S::NF; i++) fxv[i] = x[i];
@@ -269,7 +287,7 @@ ILQR_DEV void fx_of(const DevDesc& d, const double* x, double* fxv, double (*J)[
     double (*Jp)[DOF] = nullptr;
     if constexpr (WANT_J) Jp = J;
     else if constexpr (S::ND == 2) Jp = Jl;
-    if constexpr (WANT_J || S::ND == 2) fk<true>(d.chain, x, fxv, fxv + 3, Jp);
+    if constexpr (WANT_J || S::ND == 2) fk<true, ROLL>(d.chain, x, fxv, fxv + 3, Jp, lj);
     else fk<false>(d.chain, x, fxv, fxv + 3, nullptr);
     if (kpi >= 0 && d.kp_frame[kpi]) {  // TransformedSimulationInterface.cpp:53-103
         const double* R = d.kp_fR[kpi];

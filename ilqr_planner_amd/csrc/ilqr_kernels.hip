@@ -70,6 +70,9 @@ __global__ __launch_bounds__(64) void k_init_rollout(Bufs a, double penalty) {
 template <class S, bool EXT>
 __global__ __launch_bounds__(64) void k_kp_derivs(Bufs a, int fused) {
     constexpr int NX = S::NX;
+    // origins and axes of the joints and the joint angles (7 x DOF per lane) for the rolled FK loop: a short launch between the streaming kernels is bound by
+    // fetching its code, and the unrolled joints were most of it (ilqr_device.hpp: fk)
+    __shared__ double sj[7 * DOF][64];
     const DevDesc& d = *a.desc;
     const int b = blockIdx.x * 64 + threadIdx.x;
     const int kpi = blockIdx.y;
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(64) void k_kp_derivs(Bufs a, int fused) {
             x[i] = (w == 0) ? x1 : fma(aa, x1 - x[i], x[i]);
         }
     }
-    stage_derivs<S, true, EXT>(d, a, b, x, kpi, lxx, lx);
+    stage_derivs<S, true, EXT, (!S::JOINT && S::ND == 1)>(d, a, b, x, kpi, lxx, lx, &sj[0][threadIdx.x]);  // (2nd order: the rolled form spills more)
     double* out = a.kpd + (size_t)kpi * (NX + NX * NX) * Bp;
     UNR for (int i = 0; i < NX; i++) {
         AT(out, i, b) = lx[i];

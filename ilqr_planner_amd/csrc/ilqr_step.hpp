@@ -37,8 +37,8 @@ ILQR_DEV double con_g(const Bufs& a, int k, int r, const double* x, const double
 }
 
 // lx, lxx of a stage (System::cost_x / cost_xx, System.cpp:248-308).  P <- lxx, p <- lx.
-template <class S, bool WITH_LIMITS = true, bool EXT = true>
-ILQR_DEV void stage_derivs(const DevDesc& d, const Bufs& a, int b, const double* x, int kpi, double (*lxx)[S::NX], double* lx) {
+template <class S, bool WITH_LIMITS = true, bool EXT = true, bool ROLL = false>
+ILQR_DEV void stage_derivs(const DevDesc& d, const Bufs& a, int b, const double* x, int kpi, double (*lxx)[S::NX], double* lx, double* lj = nullptr) {
     constexpr int NX = S::NX, NQ = S::NQ, NF = S::NF;
     const int Bp = d.Bp;
     UNR for (int i = 0; i < NX; i++) {
@@ -66,7 +66,7 @@ ILQR_DEV void stage_derivs(const DevDesc& d, const Bufs& a, int b, const double*
         }
     } else if (kpi >= 0) {
         double fxv[NF], J[6][DOF], e[NQ], tg[NF], Qe[NQ];
-        fx_of<S, true>(d, x, fxv, J, EXT ? kpi : -1);
+        fx_of<S, true, ROLL>(d, x, fxv, J, EXT ? kpi : -1, lj);
         UNR for (int i = 0; i < NF; i++) tg[i] = AT(a.kp_tg, kpi * NF + i, b);
         kp_diff<S>(tg, fxv, e);
         if (EXT) kp_deadzone(d, kpi, e);
