@@ -428,6 +428,8 @@ __global__ void k_cpl_bcast(const double* __restrict__ wref, double* __restrict_
 template <class S, int KWP>
 __global__ __launch_bounds__(LPB) void k_cpl_linearize(Bufs a, CPArgs c) {
     constexpr int NX = S::NX;
+    constexpr int ROLL = (!S::JOINT && S::ND == 1) ? LPB : 0;  // rolled FK joint loop, its per-joint values in LDS (ilqr_device.hpp: fk)
+    __shared__ double sj[7 * DOF][LPB];
     const DevDesc& d = *a.desc;
     const int b = blockIdx.x * LPB + threadIdx.x, kpi = blockIdx.y;
     if (b >= d.B || !a.active[b]) return;
@@ -437,7 +439,7 @@ __global__ __launch_bounds__(LPB) void k_cpl_linearize(Bufs a, CPArgs c) {
     if (kpi < d.n_kp) {
         double x[NX], xp[NX], lxx[NX][NX], lx[NX], Ld[NX], ql[NX];
         cpl_states<S, KWP>(d, c, b, kpi, w, x, xp);
-        stage_derivs<S, false>(d, a, b, x, kpi, lxx, lx);  // lxx = J'QJ, lx = -J'Q e
+        stage_derivs<S, false, true, ROLL>(d, a, b, x, kpi, lxx, lx, &sj[0][threadIdx.x]);  // lxx = J'QJ, lx = -J'Q e
         if (d.kp_t[kpi] > 0) limit_terms<S>(d, xp, Ld, ql);
         else { UNR for (int r = 0; r < NX; r++) { Ld[r] = 0; ql[r] = 0; } }
         double* Ck = c.Ckp + (size_t)kpi * NX * NX * Bp;

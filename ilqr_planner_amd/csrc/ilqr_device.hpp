@@ -163,9 +163,9 @@ ILQR_DEV void kdl_quat(const double* R, double q[4]) {
 }
 
 // p, quat and (optionally) the 6x7 geometric Jacobian, columns [z_j x (p - o_j); z_j] in the base frame.
-// ROLL (with WANT_J): the joints' origins and axes go to `lj` -- wave-private LDS, entry e of this lane at lj[e * 64] -- instead of
+// ROLL > 0 (with WANT_J): the joints' origins and axes go to `lj` -- LDS, entry e of this lane at lj[e * ROLL] -- instead of
 // register arrays, so that the joint loop can stay rolled (see below); the Jacobian is formed from there with static indices.
-template <bool WANT_J, bool ROLL = false>
+template <bool WANT_J, int ROLL = 0>
 ILQR_DEV void fk(const DevChain& c, const double* q, double p[3], double quat[4], double (*J)[DOF], double* lj = nullptr) {
     double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pos[3] = {0, 0, 0};
     double org[DOF][3], ax[DOF][3];
@@ -179,7 +179,7 @@ ILQR_DEV void fk(const DevChain& c, const double* q, double p[3], double quat[4]
 #pragma unroll
             for (int i = 0; i < 3; i++) {
                 const double axi = Rn[3 * i] * x + Rn[3 * i + 1] * y + Rn[3 * i + 2] * z;
-                if constexpr (ROLL) { lj[(j * 6 + i) * 64] = pos[i]; lj[(j * 6 + 3 + i) * 64] = axi; }
+                if constexpr (ROLL) { lj[(j * 6 + i) * ROLL] = pos[i]; lj[(j * 6 + 3 + i) * ROLL] = axi; }
                 else { org[j][i] = pos[i]; ax[j][i] = axi; }
             }
         }
@@ -201,13 +201,13 @@ ILQR_DEV void fk(const DevChain& c, const double* q, double p[3], double quat[4]
         // by selects (q[] stays in registers); the chain constants are uniform loads.  Same operations in the same order: same bits.
         if constexpr (ROLL) {  // (with the Jacobian's register pressure the select chain became an indexed stack object: the angles go through LDS too)
 #pragma unroll
-            for (int i = 0; i < DOF; i++) lj[(6 * DOF + i) * 64] = q[i];
+            for (int i = 0; i < DOF; i++) lj[(6 * DOF + i) * ROLL] = q[i];
         }
 #pragma unroll 1
         for (int j = 0; j < DOF; j++) {
             double qj;
             if constexpr (ROLL) {
-                qj = lj[(6 * DOF + j) * 64];
+                qj = lj[(6 * DOF + j) * ROLL];
             } else {
                 qj = q[0];
 #pragma unroll
@@ -229,7 +229,7 @@ ILQR_DEV void fk(const DevChain& c, const double* q, double p[3], double quat[4]
 #pragma unroll
             for (int j = 0; j < DOF; j++)
 #pragma unroll
-                for (int i = 0; i < 3; i++) { org[j][i] = lj[(j * 6 + i) * 64]; ax[j][i] = lj[(j * 6 + 3 + i) * 64]; }
+                for (int i = 0; i < 3; i++) { org[j][i] = lj[(j * 6 + i) * ROLL]; ax[j][i] = lj[(j * 6 + 3 + i) * ROLL]; }
         }
 #pragma unroll
         for (int j = 0; j < DOF; j++) {
@@ -276,7 +276,7 @@ ILQR_DEV void eig_mat_to_quat(const double* m, double* q) {
 }
 
 // f(x) of getFxJac: [p; quat (; dp; dquat) (; t)]  and the 6x7 Jacobian block (the full J is blkdiag(J,J) bordered by 1)
-template <class S, bool WANT_J, bool ROLL = false>
+template <class S, bool WANT_J, int ROLL = 0>
 ILQR_DEV void fx_of(const DevDesc& d, const double* x, double* fxv, double (*J)[DOF], int kpi = -1, double* lj = nullptr) {
     if (S::JOINT) {  // JointSpacePlannerSys::getFxJac: f(x) = x (J = I is applied by the callers)
 #pragma unroll

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(64) void k_kp_derivs(Bufs a, int fused) {
             x[i] = (w == 0) ? x1 : fma(aa, x1 - x[i], x[i]);
         }
     }
-    stage_derivs<S, true, EXT, (!S::JOINT && S::ND == 1)>(d, a, b, x, kpi, lxx, lx, &sj[0][threadIdx.x]);  // (2nd order: the rolled form spills more)
+    stage_derivs<S, true, EXT, (!S::JOINT && S::ND == 1) ? 64 : 0>(d, a, b, x, kpi, lxx, lx, &sj[0][threadIdx.x]);  // (2nd order: the rolled form spills more)
     double* out = a.kpd + (size_t)kpi * (NX + NX * NX) * Bp;
     UNR for (int i = 0; i < NX; i++) {
         AT(out, i, b) = lx[i];

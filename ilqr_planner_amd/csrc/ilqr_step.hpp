@@ -37,7 +37,7 @@ ILQR_DEV double con_g(const Bufs& a, int k, int r, const double* x, const double
 }
 
 // lx, lxx of a stage (System::cost_x / cost_xx, System.cpp:248-308).  P <- lxx, p <- lx.
-template <class S, bool WITH_LIMITS = true, bool EXT = true, bool ROLL = false>
+template <class S, bool WITH_LIMITS = true, bool EXT = true, int ROLL = 0>
 ILQR_DEV void stage_derivs(const DevDesc& d, const Bufs& a, int b, const double* x, int kpi, double (*lxx)[S::NX], double* lx, double* lj = nullptr) {
     constexpr int NX = S::NX, NQ = S::NQ, NF = S::NF;
     const int Bp = d.Bp;
