@@ -25,6 +25,9 @@ using std::isnan;
 #define __forceinline__ inline __attribute__((always_inline))
 #define __noinline__ __attribute__((noinline))
 #define __launch_bounds__(...)
+// LDS of the kernels built here is lane-private scratch (k_kp_derivs: slot [entry][threadIdx.x] for the rolled FK loop); the lanes of a
+// launch run one after the other in this harness, so a static array is the same thing
+#define __shared__ static
 
 struct dim3 {
     unsigned x, y, z;
