@@ -73,6 +73,12 @@ struct Sys {
 };
 
 #define ILQR_DEV __device__ __forceinline__
+// empty statement the optimiser cannot see through (device code; tests/tools/hostsim builds the same source with g++, which has no "v" constraint)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ILQR_OPAQUE_VGPR(x) asm volatile("" : "+v"(x))
+#else
+#define ILQR_OPAQUE_VGPR(x) ((void)0)
+#endif
 
 // ------------------------------------------------------------------------------------------------ Sd (sd.h)
 ILQR_DEV double dot4(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
@@ -211,7 +217,10 @@ ILQR_DEV void fk(const DevChain& c, const double* q, double p[3], double quat[4]
             } else {
                 qj = q[0];
 #pragma unroll
-                for (int i = 1; i < DOF; i++) qj = (j == i) ? q[i] : qj;
+                for (int i = 1; i < DOF; i++) {
+                    qj = (j == i) ? q[i] : qj;
+                    ILQR_OPAQUE_VGPR(qj);  // one select at a time: the whole chain is recognised as q[j] and q[] becomes a stack object (k_select_x: 36 B)
+                }
             }
             joint(j, qj);
         }
