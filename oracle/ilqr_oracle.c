@@ -17,12 +17,17 @@
 
 /* ------------------------------------------------------------------ small dense helpers */
 
+/* Test aid (see below, orc_set_variant): bit 2 makes the three helpers accumulate with fused multiply-adds -- what a GPU (or a
+   -mfma build of Eigen) does; equal in exact arithmetic, another rounding. */
+static int g_variant = 0;
+#define ACC(s, a, b) (((g_variant) & 4) ? fma((a), (b), (s)) : ((s) + (a) * (b)))
+
 /* C(m x n) = A(m x k) * B(k x n) */
 static void mm(double* C, const double* A, const double* B, int m, int k, int n) {
     for (int i = 0; i < m; i++)
         for (int j = 0; j < n; j++) {
             double s = 0;
-            for (int l = 0; l < k; l++) s += A[i * k + l] * B[l * n + j];
+            for (int l = 0; l < k; l++) s = ACC(s, A[i * k + l], B[l * n + j]);
             C[i * n + j] = s;
         }
 }
@@ -31,13 +36,13 @@ static void mtm(double* C, const double* A, const double* B, int k, int m, int n
     for (int i = 0; i < m; i++)
         for (int j = 0; j < n; j++) {
             double s = 0;
-            for (int l = 0; l < k; l++) s += A[l * m + i] * B[l * n + j];
+            for (int l = 0; l < k; l++) s = ACC(s, A[l * m + i], B[l * n + j]);
             C[i * n + j] = s;
         }
 }
 static double dot(const double* a, const double* b, int n) {
     double s = 0;
-    for (int i = 0; i < n; i++) s += a[i] * b[i];
+    for (int i = 0; i < n; i++) s = ACC(s, a[i], b[i]);
     return s;
 }
 static double norm(const double* a, int n) { return sqrt(dot(a, a, n)); }
@@ -51,7 +56,6 @@ static int is_zero(const double* a, int n) {
 /* Eigen MatrixXd::inverse() on a dynamic-size matrix = PartialPivLU, then solve against identity. */
 /* Test aid, not part of the restated algorithm: bit 0 replaces Qxu = A'PB by Qux' in the backward sweep.  The two are equal in
    exact arithmetic; tests use the switch to show that an instance's result depends on rounding-level reassociation. */
-static int g_variant = 0;
 void orc_set_variant(int v) { g_variant = v; }
 /* Test aids (see ilqr_oracle.h): decision-margin probe and resume-from-state.  They record / seed, they change no arithmetic. */
 static __thread orc_probe_rec* g_probe = NULL;
@@ -59,7 +63,13 @@ static __thread int g_probe_cap = 0;
 static __thread int g_it0 = 0;
 static __thread double g_init_penalty = 0;
 static __thread const double* g_lambda_mask = NULL;
+static __thread int g_probe_all = 0;            /* keep evaluating the step sizes below the accepted one, for the record only */
+static __thread const double* g_resume_x = NULL; /* the trajectory the handed-over controls belong to (the caller's own rollout of them) */
+static __thread double g_resume_x_dev = 0;       /* largest |x_given - x_rolled| / max(1, |x|) seen when that trajectory was taken over */
 void orc_set_probe(orc_probe_rec* buf, int cap) { g_probe = buf; g_probe_cap = buf ? cap : 0; }
+void orc_set_probe_all(int on) { g_probe_all = on; }
+void orc_set_resume_x(const double* X) { g_resume_x = X; g_resume_x_dev = 0; }
+double orc_get_resume_x_dev(void) { return g_resume_x_dev; }
 void orc_set_resume(int it0, double init_penalty, const double* lambda_mask) { g_it0 = it0; g_init_penalty = init_penalty; g_lambda_mask = lambda_mask; }
 
 /* Test aid (variant bit 1): the inverse of a symmetric positive definite matrix by the symmetric sweep operator without pivoting --
@@ -708,6 +718,17 @@ static int solve_riccati(const orc_system* s, const orc_constraints* c, double* 
         cost0 += orc_cost(s, xk, uk, i);
         orc_step(s, xk, uk, X + (size_t)(i + 1) * nx, fX + (size_t)(i + 1) * nf,
                  As + (size_t)i * nx * nx, Bs + (size_t)i * nx * nu, NULL);
+        if (g_resume_x) { /* test aid: the caller's own rollout of these controls IS the incoming trajectory (its active-set and limit
+                             tests were taken on it); it must be this rollout up to rounding -- the deviation is reported */
+            double* xn_ = X + (size_t)(i + 1) * nx;
+            const double* xg_ = g_resume_x + (size_t)(i + 1) * nx;
+            for (int j_ = 0; j_ < nx; j_++) {
+                double dv_ = fabs(xg_[j_] - xn_[j_]) / fmax(1.0, fabs(xn_[j_]));
+                if (!(dv_ <= g_resume_x_dev)) g_resume_x_dev = dv_; /* a NaN sticks */
+                xn_[j_] = xg_[j_];
+            }
+            orc_get_fx_jac(s, xn_, fX + (size_t)(i + 1) * nf, NULL);
+        }
     }
     cost0 += orc_cost(s, X + (size_t)(T - 1) * nx, zero_u, T - 1);
 
@@ -787,7 +808,6 @@ static int solve_riccati(const orc_system* s, const orc_constraints* c, double* 
         }
 
         /* ---------------- forward pass with step-halving line search: ILQRRecursive.cpp:101-155 */
-        alpha = 2;
         double newCost = 0, dun = 0;
         orc_probe_rec* pr = (g_probe && it < g_probe_cap) ? &g_probe[it] : NULL;
         if (pr) {
@@ -795,8 +815,14 @@ static int solve_riccati(const orc_system* s, const orc_constraints* c, double* 
             pr->cost0 = cost0; pr->clamp_margin = INFINITY; pr->limit_margin = INFINITY; pr->mask_margin_in = mask_margin;
             pr->limit_margin_in = traj_limit_margin(s, X); /* l_xx of the sweep jumps where a coordinate of the incoming trajectory sits on a bound */
         }
+        /* the do/while of ILQRRecursive.cpp:101-155.  With the probe's "all trials" aid the loop goes on below the accepted step size
+           for the record only: the accepted rollout is put aside and restored (nothing of the extra trials survives). */
+        int accepted = 0;
+        double alpha_t = 2, acc_alpha = 1, acc_cost = 0, acc_dun = 0, acc_mask = INFINITY;
+        double *sv_X = NULL, *sv_fX = NULL, *sv_U = NULL, *sv_A = NULL, *sv_B = NULL, *sv_I = NULL, *sv_C = NULL;
         do {
-            alpha /= 2.0;
+            alpha_t /= 2.0;
+            const double alpha = alpha_t; /* the trial's step size (shadows the solve's: set on acceptance) */
             mask_margin = INFINITY;
             init_state(s, nX);
             orc_get_fx_jac(s, nX, nfX, NULL);
@@ -819,7 +845,26 @@ static int solve_riccati(const orc_system* s, const orc_constraints* c, double* 
             }
             newCost += orc_cost(s, nX + (size_t)(T - 1) * nx, zero_u, T - 1);
             if (pr && pr->n_trials < ORC_MAX_TRIALS) { pr->trial_alpha[pr->n_trials] = alpha; pr->trial_cost[pr->n_trials] = newCost; pr->n_trials++; }
-        } while (((newCost >= cost0) || isnan(newCost)) && alpha > 1e-3 && line_search);
+            if (!accepted && !(((newCost >= cost0) || isnan(newCost)) && alpha > 1e-3 && line_search)) {
+                accepted = 1;
+                acc_alpha = alpha; acc_cost = newCost; acc_dun = dun; acc_mask = mask_margin;
+                if (pr && g_probe_all && alpha > 1e-3 && line_search) { /* put the accepted rollout aside */
+#define SAVE_(dst, src, n) do { dst = (double*)malloc(sizeof(double) * (n)); memcpy(dst, src, sizeof(double) * (n)); } while (0)
+                    SAVE_(sv_X, nX, (size_t)T * nx); SAVE_(sv_fX, nfX, (size_t)T * nf); SAVE_(sv_U, nU, (size_t)(T - 1) * nu);
+                    SAVE_(sv_A, As, (size_t)(T - 1) * nx * nx); SAVE_(sv_B, Bs, (size_t)(T - 1) * nx * nu);
+                    if (m) { SAVE_(sv_I, Is, (size_t)(T - 1) * m); SAVE_(sv_C, Cs, (size_t)(T - 1) * m); }
+#undef SAVE_
+                }
+            }
+        } while (!accepted || (sv_X && alpha_t > 1e-3));
+        alpha = acc_alpha;
+        if (sv_X) { /* back to the accepted rollout; alpha_t ran on */
+            memcpy(nX, sv_X, sizeof(double) * T * nx); memcpy(nfX, sv_fX, sizeof(double) * T * nf); memcpy(nU, sv_U, sizeof(double) * (T - 1) * nu);
+            memcpy(As, sv_A, sizeof(double) * (T - 1) * nx * nx); memcpy(Bs, sv_B, sizeof(double) * (T - 1) * nx * nu);
+            if (m) { memcpy(Is, sv_I, sizeof(double) * (T - 1) * m); memcpy(Cs, sv_C, sizeof(double) * (T - 1) * m); }
+            free(sv_X); free(sv_fX); free(sv_U); free(sv_A); free(sv_B); free(sv_I); free(sv_C);
+        }
+        newCost = acc_cost; dun = acc_dun; mask_margin = acc_mask;
         if (pr) { /* probe: margins of the accepted rollout */
             pr->dun = dun;
             pr->mask_margin = mask_margin;
@@ -1031,17 +1076,37 @@ int orc_solve_batch_cp(const orc_system* s, const double* psi, int Kw, double* u
         mm(dw, Hi, g, Kw, Kw, 1);
         mm(du, psi, dw, NU, Kw, 1);
 
-        double alpha = 1.0;
+        orc_probe_rec* pr = (g_probe && it < g_probe_cap) ? &g_probe[it] : NULL; /* test aid: what the backtracking decided on */
+        if (pr) {
+            memset(pr, 0, sizeof(*pr));
+            pr->cost0 = cost0; pr->dun = norm(du, NU);
+            pr->mask_margin_in = pr->mask_margin = pr->clamp_margin = pr->limit_margin = INFINITY;
+            pr->limit_margin_in = INFINITY; /* (the limit tests of forwardPassWithLimits are not probed: a tie there is never excused) */
+        }
+        double alpha = 1.0, alpha_acc = 0;
+        int accepted = 0;
+        double* u_acc = NULL;
         while (1) { /* :138-158 */
             for (int k = 0; k < NU; k++) ut[k] = u[k] + alpha * du[k];
             fp_batch_run(s, ut, &ft);
             double cost = cp_cost(s, &ft, ut, NULL);
-            if ((cost < cost0) || (alpha < 1e-3)) {
-                memcpy(u, ut, sizeof(double) * NU);
-                break;
+            if (pr && pr->n_trials < ORC_MAX_TRIALS) { pr->trial_alpha[pr->n_trials] = alpha; pr->trial_cost[pr->n_trials] = cost; pr->n_trials++; }
+            if (!accepted && ((cost < cost0) || (alpha < 1e-3))) {
+                accepted = 1;
+                alpha_acc = alpha;
+                if (pr && g_probe_all && !(alpha < 1e-3)) { /* go on for the record only; the accepted controls are put aside */
+                    u_acc = (double*)malloc(sizeof(double) * NU);
+                    memcpy(u_acc, ut, sizeof(double) * NU);
+                } else {
+                    memcpy(u, ut, sizeof(double) * NU);
+                    break;
+                }
             }
+            if (accepted && alpha < 1e-3) break;
             alpha /= 2;
         }
+        if (u_acc) { memcpy(u, u_acc, sizeof(double) * NU); free(u_acc); }
+        alpha = alpha_acc;
         if (trace_cost) trace_cost[it] = cost0; /* printed cost is the PRE-step cost (:160) */
         if (trace_alpha) trace_alpha[it] = alpha;
         it_done = it + 1;

@@ -150,7 +150,8 @@ void orc_psi_linear(int dim, int K, double* out);
 
 /* general inverse by LU with partial pivoting (Eigen MatrixXd::inverse() = PartialPivLU). returns 0 ok */
 int orc_inverse(int n, const double* A, double* Ainv);
-void orc_set_variant(int v);  /* test aid: bit 0 = Qxu := Qux^T in the backward sweep (equal in exact arithmetic) */
+void orc_set_variant(int v);  /* test aid, algebraically neutral variants: bit 0 = Qxu := Qux^T in the backward sweep; bit 1 = inverses by the
+                                 pivot-free symmetric sweep operator; bit 2 = products accumulated with fused multiply-adds */
 
 /* ---- test aids for the per-instance parity proof (tests/parity_proof.py).  Not part of the restated algorithm: they only RECORD the
  * quantities the reference's discontinuous decisions are taken on, and let a solve resume from a state handed in from outside.
@@ -158,7 +159,7 @@ void orc_set_variant(int v);  /* test aid: bit 0 = Qxu := Qux^T in the backward 
 #define ORC_MAX_TRIALS 16
 typedef struct {
     double cost0;                        /* cost of the trajectory the iteration starts from (ILQRRecursive.cpp:155 compares against it) */
-    int n_trials;                        /* line-search trials run (the last one is the accepted one) */
+    int n_trials;                        /* line-search trials recorded (the last one is the accepted one unless orc_set_probe_all is on) */
     double trial_alpha[ORC_MAX_TRIALS];
     double trial_cost[ORC_MAX_TRIALS];   /* newCost of every trial */
     double dun;                          /* sum_k ||du_k|| of the accepted trial (early-stop test) */
@@ -174,6 +175,14 @@ void orc_set_probe(orc_probe_rec* buf, int cap); /* buf[it] is filled for it < c
  * that trajectory was rolled out) -- AL-ILQR.cpp:190 stores penalty * I_k at rollout time, before the update of :202-208.  it0 = 0 and
  * lambda_mask = NULL restore the plain behaviour. */
 void orc_set_resume(int it0, double init_penalty, const double* lambda_mask);
+/* Test aid: with on != 0 a probed line search (recursive / AL / Batch-CP) goes on evaluating the step sizes BELOW the accepted one,
+ * recording their costs in the probe; the solve's result is unchanged (the accepted rollout is put aside and restored). */
+void orc_set_probe_all(int on);
+/* Test aid for resumed solves: X[T][n_x] = the caller's own rollout of the controls handed over.  The oracle rolls the controls out
+ * itself, records the largest relative deviation from X (orc_get_resume_x_dev) and then takes X as the incoming trajectory, so that
+ * its active-set / limit tests are taken on the very numbers the caller's were.  NULL switches it off. */
+void orc_set_resume_x(const double* X);
+double orc_get_resume_x_dev(void);
 
 #ifdef __cplusplus
 }

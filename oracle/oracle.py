@@ -148,6 +148,12 @@ def lib():
         L.orc_set_probe.restype = None
         L.orc_set_resume.argtypes = [C.c_int, C.c_double, dp]
         L.orc_set_resume.restype = None
+        L.orc_set_probe_all.argtypes = [C.c_int]
+        L.orc_set_probe_all.restype = None
+        L.orc_set_resume_x.argtypes = [dp]
+        L.orc_set_resume_x.restype = None
+        L.orc_get_resume_x_dev.argtypes = []
+        L.orc_get_resume_x_dev.restype = C.c_double
         for n in ("orc_sd_logmap", "orc_sd_expmap"):
             getattr(L, n).argtypes = [dp, dp, dp]
         L.orc_sd_transport.argtypes = [dp, dp, dp, dp]
@@ -386,23 +392,33 @@ class _Aids:
     def __init__(self, nb_iter, probe, resume):
         self.buf = (ProbeRec * max(nb_iter, 1))() if probe else None
         self.cap = max(nb_iter, 1)
+        self.all = probe == "all"  # also record the step sizes below the accepted one
         self.resume = resume
-        self._keep = None
+        self._keep = self._keep_x = None
+        self.x_dev = None
 
     def __enter__(self):
         L = lib()
         if self.buf is not None:
             L.orc_set_probe(self.buf, self.cap)
+            L.orc_set_probe_all(1 if self.all else 0)
         if self.resume:
             lm = self.resume.get("lambda_mask")
             self._keep = _arr(lm) if lm is not None else None
-            L.orc_set_resume(int(self.resume["it0"]), float(self.resume.get("init_penalty", 0.0)), _dp(self._keep))
+            L.orc_set_resume(int(self.resume.get("it0", 0)), float(self.resume.get("init_penalty", 0.0)), _dp(self._keep))
+            if self.resume.get("X") is not None:  # the caller's own rollout of the controls handed over
+                self._keep_x = _arr(self.resume["X"])
+                L.orc_set_resume_x(_dp(self._keep_x))
         return self
 
     def __exit__(self, *exc):
         L = lib()
+        if self._keep_x is not None:
+            self.x_dev = float(L.orc_get_resume_x_dev())
         L.orc_set_probe(None, 0)
+        L.orc_set_probe_all(0)
         L.orc_set_resume(0, 0.0, None)
+        L.orc_set_resume_x(None)
 
     def records(self, n):
         if self.buf is None:
@@ -426,7 +442,7 @@ def solve_recursive(s: System, U0, nb_iter, line_search=True, early_stop=True, p
     with _Aids(nb_iter, probe, resume) as aids:
         n = lib().orc_solve_recursive(C.byref(s), _dp(U0), nb_iter, int(line_search), int(early_stop), _dp(X), _dp(fX), _dp(U),
                                       _dp(K), _dp(d), _dp(cost_), _dp(tc), _dp(ta))
-    return dict(X=X, fX=fX, U=U, K=K, d=d, cost=float(cost_[0]), iters=n, trace_cost=tc[:n], trace_alpha=ta[:n], probe=aids.records(n))
+    return dict(X=X, fX=fX, U=U, K=K, d=d, cost=float(cost_[0]), iters=n, trace_cost=tc[:n], trace_alpha=ta[:n], probe=aids.records(n), x_dev=aids.x_dev)
 
 
 def solve_al(s: System, A, b, lambda0, U0, nb_iter, lag_update_step, penalty, scaling, line_search=True, early_stop=True, probe=False, resume=None):
@@ -445,23 +461,26 @@ def solve_al(s: System, A, b, lambda0, U0, nb_iter, lag_update_step, penalty, sc
     with _Aids(nb_iter, probe, resume) as aids:
         n = lib().orc_solve_al(C.byref(s), C.byref(c), _dp(lam), _dp(U0), nb_iter, lag_update_step, penalty, scaling,
                                int(line_search), int(early_stop), _dp(X), _dp(fX), _dp(U), _dp(cost_), _dp(tc), _dp(ta))
-    return dict(X=X, fX=fX, U=U, cost=float(cost_[0]), iters=n, trace_cost=tc[:n], trace_alpha=ta[:n], lam=lam, probe=aids.records(n))
+    return dict(X=X, fX=fX, U=U, cost=float(cost_[0]), iters=n, trace_cost=tc[:n], trace_alpha=ta[:n], lam=lam, probe=aids.records(n), x_dev=aids.x_dev)
 
 
-def solve_batch_cp(s: System, psi, u0, nb_iter, early_stop=True):
+def solve_batch_cp(s: System, psi, u0, nb_iter, early_stop=True, probe=False):
+    """probe: True = per-iteration record of what the backtracking decided on (pre-step cost, every trial's step size and cost,
+    ||du||); "all" = the trials below the accepted step size as well (test aids, ilqr_oracle.h)."""
     T, nu = s.T, s.n_u
     psi = _arr(psi)
     assert psi.shape[0] == (T - 1) * nu
     u = _arr(u0, (T - 1) * nu).copy()
     tc, ta = np.full(max(nb_iter, 1), np.nan), np.full(max(nb_iter, 1), np.nan)
-    n = lib().orc_solve_batch_cp(C.byref(s), _dp(psi), psi.shape[1], _dp(u), nb_iter, int(early_stop), _dp(tc), _dp(ta))
-    return dict(u=u, iters=n, trace_cost=tc[:n], trace_alpha=ta[:n])
+    with _Aids(nb_iter, probe, None) as aids:
+        n = lib().orc_solve_batch_cp(C.byref(s), _dp(psi), psi.shape[1], _dp(u), nb_iter, int(early_stop), _dp(tc), _dp(ta))
+    return dict(u=u, iters=n, trace_cost=tc[:n], trace_alpha=ta[:n], probe=aids.records(n))
 
 
-def solve_batch(s: System, u0, nb_iter, early_stop=True):
+def solve_batch(s: System, u0, nb_iter, early_stop=True, probe=False):
     """BatchILQR::solve (reference src/solver/BatchILQR.cpp:110-173).  The file differs from BatchILQRCP.cpp only in the absence
     of PSI (lstq_A = Su'(J'QJ+L)Su + R, du = lstq_A^-1 lstq_B): it is the control-primitive solver with PSI = I, run as such."""
-    return solve_batch_cp(s, np.eye((s.T - 1) * s.n_u), u0, nb_iter, early_stop)
+    return solve_batch_cp(s, np.eye((s.T - 1) * s.n_u), u0, nb_iter, early_stop, probe)
 
 
 def psi(kind: str, dim: int, K: int):
@@ -479,5 +498,7 @@ def inverse(A):
 
 
 def set_variant(v: int):
-    """Test aid: bit 0 makes the backward sweep use Qxu := Qux^T (equal to A'PB in exact arithmetic)."""
+    """Test aid, algebraically neutral variants of the restated arithmetic: bit 0 makes the backward sweep use Qxu := Qux^T (equal to
+    A'PB in exact arithmetic), bit 1 inverts by the pivot-free symmetric sweep operator instead of partial-pivot LU, bit 2 accumulates
+    every product with fused multiply-adds."""
     lib().orc_set_variant(int(v))

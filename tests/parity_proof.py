@@ -1,25 +1,34 @@
-"""Per-instance parity proof for the Riccati solvers (ILQRRecursive / AL_ILQR) -- test infrastructure, uses the oracle.
+"""Per-instance parity proof for the Riccati solvers (ILQRRecursive / AL_ILQR) and the batch solvers (BatchILQRCP / BatchILQR) --
+test infrastructure, uses the oracle.
 
 Why a final-cost comparison alone cannot be the gate.  The reference's iteration is a DISCONTINUOUS and, far from convergence,
-strongly expanding map: the line search accepts the first step size whose cost is below the previous one (ILQRRecursive.cpp:155) and
-accepts the last one anyway; AL_ILQR masks a row when `g < 0 && lambda == 0` (AL-ILQR.cpp:38-42) and clamps the multipliers at zero
-(:205).  Two correct implementations with different rounding (FMA contraction, another libm, an algebraically equivalent sweep) can
-therefore part ways on some instances and end at different costs.  What CAN be checked, instance by instance and iteration by
-iteration, is that every iteration the GPU made is the reference's iteration:
+strongly expanding map: the line search accepts the first step size whose cost is below the previous one (ILQRRecursive.cpp:155,
+BatchILQRCP.cpp:152) and accepts the last one anyway; AL_ILQR masks a row when `g < 0 && lambda == 0` (AL-ILQR.cpp:38-42) and clamps
+the multipliers at zero (:205).  Two correct implementations with different rounding (FMA contraction, another libm, an
+algebraically equivalent sweep) can therefore part ways on some instances and end at different costs.  What CAN be checked, instance
+by instance and iteration by iteration, is that every iteration the GPU made is the reference's iteration:
 
   for it = 0 .. iters-1:
-      take the GPU's own state after `it` iterations  (U_it, and for AL the multipliers lambda_it and lambda_{it-1})
-      run ONE oracle iteration from that state        (orc_set_resume: same iteration index, same penalties, same mask inputs)
-      the oracle's (cost, alpha) must equal the GPU's trace entry `it`:   same alpha and |dcost| <= STEP_RTOL * |cost|
-      -- or the oracle's own decision at that iteration must be a TIE: the line-search trial at which the two part has
-         |newCost - cost0| <= TIE_RTOL * |cost0| (the comparison is decided by rounding), or an active-set / clamp / limit test
-         sits within MASK_ATOL of its threshold (orc_probe_rec).
+      take the GPU's own state after `it` iterations  (U_it and its own rollout X_it of them; for AL the multipliers lambda_it, lambda_{it-1})
+      run ONE oracle iteration from that state        (orc_set_resume / orc_set_resume_x: same iteration index, same penalties, the
+                                                       active-set and limit tests taken on the very numbers the GPU's were)
+      with every step size of the schedule evaluated  (orc_set_probe_all), and require
+        (a) the oracle's cost of the state = the GPU's previous trace entry            (COST0_RTOL)
+        (b) the GPU's decisions follow from the ORACLE's trial costs: every step size the GPU rejected has oracle cost >= cost0 (or
+            NaN), the one it accepted has oracle cost < cost0 (or is the floor) -- a comparison may go the other way only if it is
+            decided by rounding, |cost - cost0| <= TIE_RTOL |cost0|                    (constructive: the branch the GPU took is evaluated)
+        (c) the oracle's cost AT THE GPU's step size = the GPU's trace entry            (STEP_RTOL; or, for an ill-conditioned sweep, a
+            deviation no larger than what the oracle's own algebraically neutral variants move that very number)
+        (d) with early stop: the stop / go-on decision follows from the oracle's ||du|| the same way (STOP_RTOL).
 
-An instance whose every iteration passes is PROVEN: its GPU trajectory is a chain of reference iterations (up to rounding-level
-ties), and any distance between its final cost and the oracle's own end-to-end run is the reference map's own sensitivity.  An
-iteration that fails both tests is a kernel bug.  The GPU states come from deterministic re-runs with nb_iter = it (the kernels use
-no atomics: a solve with fewer iterations reproduces the prefix of a longer one bit for bit, which the proof also checks through the
-cost the oracle's re-rollout of U_it must reproduce).
+An instance whose every iteration passes is PROVEN: its GPU trajectory is a chain of reference iterations, and any distance between its
+final cost and the oracle's own end-to-end run is the reference map's own sensitivity.  An iteration that fails is a kernel bug.
+Nothing is excused on a margin alone any more (round 2 accepted an active-set or limit test within 1e-12 of its threshold without
+checking the other branch): with the GPU's own trajectory handed over, those tests see identical numbers on both sides.  The one
+exception left is an AL row with more than one non-zero coefficient, whose value g = A [x; u] - b is a sum formed in another order on
+the GPU: there a mask test within MASK_ATOL of zero is a tie, and it is counted.  The GPU states come from deterministic re-runs with
+nb_iter = it (the kernels use no atomics: a solve with fewer iterations reproduces the prefix of a longer one bit for bit, which the
+proof also checks through (a)).
 """
 from __future__ import annotations
 
@@ -28,119 +37,202 @@ import numpy as np
 from tests.helpers import oracle_system_of_instance, orc, panda_segs
 
 STEP_RTOL = 1e-9    # one iteration from the same state: relative cost agreement (measured on MI355X over 2e4 steps of every system
-                    # shape and both kernel sets: median 1e-13, p99 2e-11, max 5e-10 -- profiles/r02_parity_probe.json)
-STEP_RTOL_ILL = 1e-3  # ... up to here if the oracle's own rounding sensitivity at that step explains it: algebraically neutral variants of
-                    # its sweep (Qxu := Qux^T; Quu inverted by the pivot-free symmetric sweep operator instead of partial-pivot LU -- both
-                    # equal in exact arithmetic, orc_set_variant bits 0 and 1) move the step's cost by at least 1/100 of the GPU's
-                    # deviation.  Time-system instances reach cond(Quu) ~ 1e9: one iteration then amplifies 1e-16 to 1e-7 .. 1e-5.
-COST0_RTOL = 1e-9   # the oracle's re-rollout of the GPU's controls must reproduce the GPU's accepted cost (measured max 9e-11)
+                    # shape and both kernel sets: median 1e-13, p99 2e-11, max 5e-10 -- profiles/r02_parity_probe_c3.json)
+STEP_RTOL_ILL = 1e-3  # ... up to here ONLY if the oracle's own rounding sensitivity at that step is at least as large: algebraically
+                    # neutral variants of its arithmetic (orc_set_variant: Qxu := Qux^T; inverses by the pivot-free symmetric sweep
+                    # operator instead of partial-pivot LU; products accumulated with fused multiply-adds; and their combinations) move
+                    # the same number by >= the GPU's deviation.  Time-system instances reach cond(Quu) ~ 1e9: one iteration then
+                    # amplifies 1e-16 to 1e-7 .. 1e-5.  (Round 2 accepted 100x the measured sensitivity; no factor now.)
+VARIANTS = (1, 2, 3, 4, 5, 6, 7)
+COST0_RTOL = 1e-9   # the oracle's cost of the GPU's state must reproduce the GPU's accepted cost (measured max 9e-11)
+XDEV_TOL = 1e-9     # the GPU's trajectory must be the oracle's rollout of the GPU's controls: max |dx| / max(1, |x|)
 TIE_RTOL = 1e-9     # a line-search comparison newCost < cost0 is a tie when |newCost - cost0| / |cost0| is below the step agreement
-MASK_ATOL = 1e-12   # an active-set (g < 0 with lambda == 0), clamp (lambda + penalty g > 0) or limit (x > max) test is a tie within
-                    # this distance of its threshold: 4500 eps -- the measured ties sit at |g| <= 3e-15, where AL_ILQR rides the bound
-                    # (lambda = 0, g = +-1 ulp over a run of timesteps: the penalty is switched by the sign of rounding noise)
+MASK_ATOL = 1e-12   # AL rows with several non-zero coefficients only (see the header)
 STOP_RTOL = 1e-9    # early-stop tests alpha sqrt(sum ||du||) < 1e-3 and cost < 1e-3: relative distance to the threshold
+ALPHA_FLOOR = 1e-3  # ILQRRecursive.cpp:155 / BatchILQRCP.cpp:152
 
 
-def gpu_states(p, cfg, nb_iter, early_stop, run_solver):
-    """U (and lambda) of the whole batch after 0 .. nb_iter-1 iterations, from re-runs with fewer iterations."""
+def _unpad(cfg, inp, a):
+    """Device arrays of joint-space batches are padded to 7 joints; the oracle works on the true number."""
+    if cfg["kind"] in (2, 3) and inp.get("dof", 7) < 7:
+        n = inp["dof"]
+        a = np.concatenate([a[..., :n], a[..., 7:]], axis=-1)
+    return np.ascontiguousarray(a)
+
+
+def gpu_states(p, cfg, nb_iter, early_stop, run_solver, upto=None):
+    """U, X (and lambda) of the whole batch after 0 .. nb_iter-1 iterations, from re-runs with fewer iterations (early stop off: a
+    stopped instance's prefix is the same)."""
     out = []
     al = cfg["solver"] == "al"
-    for it in range(nb_iter):
+    for it in range(nb_iter if upto is None else upto):
         if al:
             p.reset_multipliers()
         run_solver(p, cfg, nb_iter=it, early_stop=early_stop)
-        out.append(dict(U=p.U(), lam=p.lam() if al else None))
+        out.append(dict(U=p.U(), X=p.X(), lam=p.lam() if al else None))
     return out
 
 
 def _u_oracle(cfg, inp, U):
-    if cfg["kind"] in (2, 3) and inp.get("dof", 7) < 7:  # joint-space batches are padded to 7 joints on the device only
-        n = inp["dof"]
-        U = np.hstack([U[:, :n], U[:, 7:]])
-    return U.reshape(-1)
+    return _unpad(cfg, inp, U).reshape(-1)
 
 
-def one_step(cfg, inp, i, it, states, segs=None, sysm=None):
+def one_step(cfg, inp, i, it, states, segs=None, sysm=None, probe="all"):
     """One oracle iteration (index `it`) of instance i from the GPU's state after `it` iterations.  Returns the oracle result."""
     s = sysm or oracle_system_of_instance(cfg, inp, i, segs)
     U = _u_oracle(cfg, inp, states[it]["U"][i])
+    X = _unpad(cfg, inp, states[it]["X"][i]) if states[it].get("X") is not None else None
     if cfg["solver"] == "recursive":
-        return orc.solve_recursive(s, U, 1, True, False, probe=True, resume=dict(it0=it) if it else None)
+        return orc.solve_recursive(s, U, 1, True, False, probe=probe, resume=dict(it0=it, X=X))
     al = cfg["al"]
     pen = al["penalty"] * al["scaling"] ** (it // al["lag"])          # penalty in force during iteration `it`
     pen_in = al["penalty"] * al["scaling"] ** ((it - 1) // al["lag"]) if it else pen  # ... when the incoming trajectory was rolled out
-    res = dict(it0=it, init_penalty=pen_in, lambda_mask=states[it - 1]["lam"][i]) if it else None
-    return orc.solve_al(s, inp["A"], inp["b"], states[it]["lam"][i], U, 1, al["lag"], pen, al["scaling"], True, False, probe=True, resume=res)
+    res = dict(it0=it, init_penalty=pen_in, lambda_mask=states[it - 1]["lam"][i] if it else None, X=X)
+    return orc.solve_al(s, inp["A"], inp["b"], states[it]["lam"][i], U, 1, al["lag"], pen, al["scaling"], True, False, probe=probe, resume=res)
+
+
+def _rel(a, b):
+    fa, fb = np.isfinite(a), np.isfinite(b)
+    if not fa and not fb:
+        return 0.0
+    if fa != fb:
+        return np.inf  # NaN on one side only: never excused
+    return abs(a - b) / max(abs(b), 1e-300)
+
+
+def decisions_follow(pr, ag, line_search=True, floor_strict=False):
+    """(b) of the header.  pr: oracle probe record with ALL trials; ag: the step size the GPU accepted.  Returns (ok, ties, detail):
+    ties = number of comparisons that go the other way within TIE_RTOL.  floor_strict: the batch solvers stop at alpha < 1e-3
+    (BatchILQRCP.cpp:152), the recursive ones go on while alpha > 1e-3 (ILQRRecursive.cpp:155) -- the same last step size 2^-10."""
+    c0 = pr["cost0"]
+    ties = 0
+    for a, c in zip(pr["alpha"], pr["cost"]):
+        near = np.isfinite(c) and np.isfinite(c0) and abs(c - c0) <= TIE_RTOL * abs(c0)
+        if floor_strict:  # BatchILQRCP.cpp:152: if ((cost < cost0) || (alpha < 1e-3)) accept
+            at_floor, improves = a < ALPHA_FLOOR, bool(c < c0)
+        else:             # ILQRRecursive.cpp:155: while (((newCost >= cost0) || isNaN(newCost)) && alpha > 1e-3 && line_search)
+            at_floor, improves = not (a > ALPHA_FLOOR), not (bool(c >= c0) or np.isnan(c))
+        if a > ag:  # the GPU rejected this step size
+            if at_floor or not line_search:
+                return False, ties, dict(alpha=a, why="went below the floor")
+            if improves:
+                if not near:
+                    return False, ties, dict(alpha=a, cost=c, cost0=c0, why="rejected an improving step")
+                ties += 1
+        elif a == ag:  # ... and accepted this one
+            if not (improves or at_floor or not line_search):
+                if not near:
+                    return False, ties, dict(alpha=a, cost=c, cost0=c0, why="accepted a non-improving step above the floor")
+                ties += 1
+            return True, ties, None
+    return False, ties, dict(alpha=ag, why="step size not in the schedule")
+
+
+def _variant_sensitivity(run, pick, ref):
+    """Largest relative move of pick(result) over the oracle's neutral variants; inf if a variant changes what pick cannot compare."""
+    sens = 0.0
+    for var in VARIANTS:
+        orc.set_variant(var)
+        try:
+            v = pick(run())
+        finally:
+            orc.set_variant(0)
+        if v is None or not np.isfinite(v):
+            return np.inf
+        sens = max(sens, abs(v - ref) / max(abs(ref), 1e-300))
+    return sens
+
+
+def _cost_at(pr, a):
+    for al, c in zip(pr["alpha"], pr["cost"]):
+        if al == a:
+            return c
+    return None
+
+
+def _multi_nonzero_rows(cfg, inp):
+    return cfg["solver"] == "al" and bool(np.any(np.count_nonzero(np.asarray(inp["A"]).reshape(-1, np.asarray(inp["A"]).shape[-1]), axis=1) > 1))
 
 
 def prove_instance(cfg, inp, i, states, ct, at, iters, segs=None, nb_iter=None, early_stop=False):
-    """Classifies instance i.  ct, at: the GPU's cost / alpha traces [B][nb_iter]; iters: iterations the GPU ran.
-    Returns dict(verdict = 'stepwise' | 'tie' | 'unexplained', steps = [...]) -- 'stepwise': every iteration reproduced;
-    'tie': every iteration reproduced or decided by a rounding-level tie in the oracle's own decision.
+    """Classifies instance i of a Riccati solve.  ct, at: the GPU's cost / alpha traces [B][nb_iter]; iters: iterations the GPU ran.
+    Returns dict(verdict = 'stepwise' | 'tie' | 'unexplained', steps = [...], n_ties, n_ill, worst_ill_ratio) -- 'stepwise': every
+    iteration reproduced; 'tie': every iteration reproduced, some decision taken inside the rounding of the oracle's own comparison.
     With early_stop the stop / go-on decision after every iteration is checked the same way (nb_iter = the solve's iteration cap)."""
     segs = segs or panda_segs()
     s = oracle_system_of_instance(cfg, inp, i, segs)
     steps, verdict = [], "stepwise"
     n = int(iters[i])
     nb_iter = int(nb_iter if nb_iter is not None else ct.shape[1])
+    n_ties = n_ill = 0
+    worst_ratio = 0.0
+    multi = _multi_nonzero_rows(cfg, inp)
     for it in range(n):
         r = one_step(cfg, inp, i, it, states, segs, s)
         pr = r["probe"][0]
         cg, ag = float(ct[i, it]), float(at[i, it])
-        co, ao = float(r["trace_cost"][0]), float(r["trace_alpha"][0])
-        st = dict(it=it, alpha_gpu=ag, alpha_orc=ao, cost_gpu=cg, cost_orc=co)
-        # the state handed over is the GPU's accepted trajectory of the previous iteration: its cost must be the GPU's previous trace entry
+        ao = float(r["trace_alpha"][0])
+        st = dict(it=it, alpha_gpu=ag, alpha_orc=ao, cost_gpu=cg, cost_orc=float(r["trace_cost"][0]))
+        fails = []
+        # the state handed over: its trajectory is the rollout of its controls, and its cost is the GPU's previous trace entry
+        xdev = r.get("x_dev")
+        if xdev is not None:
+            st["x_dev"] = xdev
+            if not (xdev <= XDEV_TOL) and np.all(np.isfinite(states[it]["X"][i])):
+                fails.append("x_dev")
         if it > 0 and np.isfinite(ct[i, it - 1]):
-            st["cost0_rel"] = abs(pr["cost0"] - ct[i, it - 1]) / max(abs(ct[i, it - 1]), 1e-300)
-        nan_both = (not np.isfinite(cg)) and (not np.isfinite(co))
-        rel = 0.0 if nan_both else (abs(cg - co) / max(abs(co), 1e-300) if np.isfinite(cg) and np.isfinite(co) else np.inf)
+            st["cost0_rel"] = _rel(pr["cost0"], float(ct[i, it - 1]))
+            if st["cost0_rel"] > COST0_RTOL:
+                fails.append("cost0")
+        # (b) decisions from the oracle's own trial costs
+        ok, ties, why = decisions_follow(pr, ag)
+        if not ok:
+            if multi and pr["mask_margin_in"] <= MASK_ATOL:  # g of a multi-coefficient row is a sum in another order on the GPU
+                ties += 1
+                st["mask_tie"] = pr["mask_margin_in"]
+            else:
+                fails.append("decision")
+                st["decision"] = why
+        # (c) the cost at the GPU's step size
+        co_at = _cost_at(pr, ag)
+        rel = _rel(cg, co_at) if co_at is not None else np.inf
         st["rel"] = rel
-        margins = dict(mask_in=pr["mask_margin_in"], limit_in=pr["limit_margin_in"])  # what this iteration's sweep switches on
-        ill = False
-        if ag == ao and STEP_RTOL < rel <= STEP_RTOL_ILL:  # an ill-conditioned sweep?  ask the oracle how much its own rounding moves this step
-            sens = 0.0
-            for var in (1, 2, 3):
-                orc.set_variant(var)
-                try:
-                    rv = one_step(cfg, inp, i, it, states, segs, s)
-                finally:
-                    orc.set_variant(0)
-                cv = float(rv["trace_cost"][0])
-                if float(rv["trace_alpha"][0]) != ao or not np.isfinite(cv):
-                    sens = np.inf  # the variant even changes the accepted step size
+        if rel > STEP_RTOL:
+            ill = False
+            if rel <= STEP_RTOL_ILL:
+                sens = _variant_sensitivity(lambda: one_step(cfg, inp, i, it, states, segs, s), lambda rv: _cost_at(rv["probe"][0], ag), co_at)
+                st["variant_rel"] = sens
+                ill = sens >= rel
+                if ill:
+                    n_ill += 1
+                    worst_ratio = max(worst_ratio, rel / sens if np.isfinite(sens) and sens > 0 else 0.0)
+            if not ill:
+                if multi and pr["mask_margin_in"] <= MASK_ATOL and "mask_tie" not in st:
+                    ties += 1
+                    st["mask_tie"] = pr["mask_margin_in"]
                 else:
-                    sens = max(sens, abs(cv - co) / max(abs(co), 1e-300))
-            st["variant_rel"] = sens
-            ill = sens >= rel / 100
-        if ag == ao and (rel <= STEP_RTOL or ill) and st.get("cost0_rel", 0.0) <= COST0_RTOL:
-            st["how"] = "same" if not ill else "same:ill-conditioned"
-        else:
-            how = None
-            if ag != ao:  # the trial at which they part: the larger of the two step sizes (one accepted it, the other went on halving)
-                a_hi = max(ag, ao)
-                t = [k for k, a in enumerate(pr["alpha"]) if a == a_hi]
-                if t:
-                    c_t = pr["cost"][t[0]]
-                    st["tie_margin"] = abs(c_t - pr["cost0"]) / max(abs(pr["cost0"]), 1e-300) if np.isfinite(c_t) else np.inf
-                    if st["tie_margin"] <= TIE_RTOL:
-                        how = "tie:line-search"
-            if how is None and min(margins.values()) <= MASK_ATOL:
-                how = "tie:" + min(margins, key=margins.get)
-            st["how"] = how or "FAIL"
-            st["margins"] = margins
-            verdict = "unexplained" if how is None else ("tie" if verdict != "unexplained" else verdict)
-        if early_stop and st["how"] != "FAIL" and it < nb_iter - 1:  # (after the last allowed iteration the decision leaves no trace)
+                    fails.append("cost")
+        st["how"] = "FAIL:" + ",".join(fails) if fails else ("tie" if ties else ("same" if rel <= STEP_RTOL else "same:ill-conditioned"))
+        n_ties += ties
+        if fails:
+            verdict = "unexplained"
+        elif ties and verdict != "unexplained":
+            verdict = "tie"
+        if early_stop and not fails and it < nb_iter - 1 and ag == ao:  # (after the last allowed iteration the decision leaves no trace)
             # the stop decision taken on this iteration's result (ILQRRecursive.cpp:174-176, AL-ILQR.cpp:225)
             crit = ao * np.sqrt(pr["dun"])
+            co = float(r["trace_cost"][0])
             stop_o = crit < 1e-3 and (cfg["solver"] == "al" or co < 1e-3)
             stop_g = (it == n - 1) and (n < nb_iter)
-            if stop_o != stop_g and ag == ao:
+            if stop_o != stop_g:
                 near = abs(crit - 1e-3) <= STOP_RTOL * 1e-3 or (cfg["solver"] != "al" and abs(co - 1e-3) <= STOP_RTOL * 1e-3)
                 st["stop"] = "tie:early-stop" if near else "FAIL"
                 st["stop_crit"] = float(crit)
+                if near:
+                    n_ties += 1
                 verdict = "unexplained" if not near else ("tie" if verdict != "unexplained" else verdict)
         steps.append(st)
-    return dict(verdict=verdict, steps=steps)
+    return dict(verdict=verdict, steps=steps, n_ties=n_ties, n_ill=n_ill, worst_ill_ratio=worst_ratio)
 
 
 def check_batch(p, cfg, inp, nb_iter, early_stop, run_solver, oracle_solve, always=(0, 1, 2, 3), rtol=1e-4, indices=None):
@@ -163,24 +255,154 @@ def check_batch(p, cfg, inp, nb_iter, early_stop, run_solver, oracle_solve, alwa
             rel[i] = np.inf  # NaN on one side only: never excused, must be proven step by step
         if rel[i] > rtol or i in always:
             flagged.append(i)
-    states = gpu_states(p, cfg, nb_iter, early_stop, run_solver) if flagged else None
+    states = gpu_states(p, cfg, nb_iter, False, run_solver, upto=int(max(iters[flagged])) if flagged else 0) if flagged else None
     results, failures = [], []
     proofs = {i: prove_instance(cfg, inp, i, states, ct, at, iters, segs, nb_iter, early_stop) for i in flagged}
     for i in todo:
         results.append((rel[i] <= rtol, proofs.get(i)))
         pf = proofs.get(i)
         if pf and pf["verdict"] == "unexplained":
-            failures.append(dict(i=i, rel=float(rel[i]), steps=[st for st in pf["steps"] if st["how"] == "FAIL" or st.get("stop") == "FAIL"]))
+            failures.append(dict(i=i, rel=float(rel[i]), steps=[st for st in pf["steps"] if st["how"].startswith("FAIL") or st.get("stop") == "FAIL"]))
     summ = summarize(results)
     summ["n_proven_always"] = sum(1 for i in always if i in proofs and proofs[i]["verdict"] != "unexplained")
     return summ, rel, failures
 
 
 def summarize(results):
-    """Fractions over a list of (within_1e4: bool, proof or None) pairs."""
+    """Fractions over a list of (within_1e4: bool, proof or None) pairs, plus what the proofs leaned on: the number of decisions
+    taken inside the rounding of the oracle's own comparison (ties) and of steps accepted as ill-conditioned, with the worst ratio of
+    the GPU's deviation to the oracle's own variant sensitivity (<= 1 by construction)."""
     n = len(results)
     within = sum(1 for w, _ in results if w)
     tie = sum(1 for w, pf in results if not w and pf and pf["verdict"] == "tie")
     stepwise = sum(1 for w, pf in results if not w and pf and pf["verdict"] == "stepwise")
     unexpl = n - within - tie - stepwise
-    return dict(n=n, frac_within_1e4=within / n, frac_proven_tie=tie / n, frac_proven_stepwise=stepwise / n, frac_unexplained=unexpl / n)
+    proofs = [pf for _, pf in results if pf]
+    return dict(n=n, frac_within_1e4=within / n, frac_proven_tie=tie / n, frac_proven_stepwise=stepwise / n, frac_unexplained=unexpl / n,
+                n_proofs=len(proofs), n_steps_checked=sum(len(pf["steps"]) for pf in proofs), n_tie_decisions=sum(pf["n_ties"] for pf in proofs),
+                n_steps_ill_conditioned=sum(pf["n_ill"] for pf in proofs), worst_ill_ratio=max([pf["worst_ill_ratio"] for pf in proofs], default=0.0))
+
+
+# ----------------------------------------------------------------------------- batch solvers (BatchILQRCP / BatchILQR)
+
+
+def gpu_states_batch(p, solve, nb_iter):
+    """Controls of the whole batch after 0 .. nb_iter iterations, and the cost / alpha traces of nb_iter + 1 iterations -- all from
+    re-runs WITHOUT early stop (the solves restart from the U0 of the problem; a stopped instance's prefix is the same).
+    solve(p, n, early_stop) runs the batch solver under test."""
+    states = []
+    for it in range(nb_iter + 1):
+        solve(p, it, False)
+        states.append(dict(U=p.U()))
+    solve(p, nb_iter + 1, False)
+    ct, at = p.trace(nb_iter + 1)
+    return states, ct, at
+
+
+def prove_instance_batch(cfg, inp, i, psi, states, ct_ext, at_ext, n, early_stop, nb_iter, segs=None):
+    """Classifies instance i of a BatchILQRCP / BatchILQR solve (psi = None: identity basis, BatchILQR.cpp:110-173).  The solver's state
+    is its control vector alone (BatchILQRCP.cpp:109-175 keeps nothing else across iterations), so one oracle iteration from the GPU's
+    controls after `it` iterations must give: the GPU's printed (pre-step) cost, decisions that follow from the oracle's trial costs,
+    and -- at the GPU's step size -- the pre-step cost the GPU prints at iteration it + 1 (ct_ext has nb_iter + 1 entries)."""
+    segs = segs or panda_segs()
+    s = oracle_system_of_instance(cfg, inp, i, segs)
+    steps, verdict = [], "stepwise"
+    n_ties = n_ill = 0
+    worst_ratio = 0.0
+
+    def run(it):
+        u = _u_oracle(cfg, inp, states[it]["U"][i])
+        return orc.solve_batch(s, u, 1, False, probe="all") if psi is None else orc.solve_batch_cp(s, psi, u, 1, False, probe="all")
+
+    for it in range(int(n)):
+        r = run(it)
+        pr = r["probe"][0]
+        ag, ao = float(at_ext[i, it]), float(r["trace_alpha"][0])
+        st = dict(it=it, alpha_gpu=ag, alpha_orc=ao, cost0_gpu=float(ct_ext[i, it]), cost0_orc=pr["cost0"])
+        fails = []
+        st["cost0_rel"] = _rel(float(ct_ext[i, it]), pr["cost0"])
+        if st["cost0_rel"] > COST0_RTOL:
+            fails.append("cost0")
+        ok, ties, why = decisions_follow(pr, ag, floor_strict=True)
+        if not ok:
+            fails.append("decision")
+            st["decision"] = why
+        co_at = _cost_at(pr, ag)
+        cg_next = float(ct_ext[i, it + 1])
+        rel = _rel(cg_next, co_at) if co_at is not None else np.inf
+        st["rel"] = rel
+        if rel > STEP_RTOL:
+            ill = False
+            if rel <= STEP_RTOL_ILL:  # the normal equations are ill-conditioned (R = 1e-5 against J'QJ ~ 1; overlapping bases)
+                sens = _variant_sensitivity(lambda: run(it), lambda rv: _cost_at(rv["probe"][0], ag), co_at)
+                st["variant_rel"] = sens
+                ill = sens >= rel
+                if ill:
+                    n_ill += 1
+                    worst_ratio = max(worst_ratio, rel / sens if np.isfinite(sens) and sens > 0 else 0.0)
+            if not ill:
+                fails.append("cost")
+        st["how"] = "FAIL:" + ",".join(fails) if fails else ("tie" if ties else ("same" if rel <= STEP_RTOL else "same:ill-conditioned"))
+        n_ties += ties
+        if fails:
+            verdict = "unexplained"
+        elif ties and verdict != "unexplained":
+            verdict = "tie"
+        if early_stop and not fails and it < nb_iter - 1 and ag == ao:  # BatchILQRCP.cpp:167
+            crit = ao * pr["dun"]
+            stop_o = crit < 1e-3
+            stop_g = (it == n - 1) and (n < nb_iter)
+            if stop_o != stop_g:
+                near = abs(crit - 1e-3) <= STOP_RTOL * 1e-3
+                st["stop"] = "tie:early-stop" if near else "FAIL"
+                if near:
+                    n_ties += 1
+                verdict = "unexplained" if not near else ("tie" if verdict != "unexplained" else verdict)
+        steps.append(st)
+    return dict(verdict=verdict, steps=steps, n_ties=n_ties, n_ill=n_ill, worst_ill_ratio=worst_ratio)
+
+
+def check_batch_solver(p, cfg, inp, psi, nb_iter, early_stop, solve, always=(0, 1), rtol=1e-4, indices=None):
+    """The parity gate of the batch solvers: `p` has been solved with solve(p, nb_iter, early_stop).  Every instance (of `indices`) has
+    the oracle's step-size sequence and a cost trace within `rtol` of the oracle's own end-to-end run, or is PROVEN iteration by
+    iteration; the instances in `always` are proven whatever their distance.  No share of a batch is excused.  Returns
+    (summary, rel, failures, oracle_runs)."""
+    iters = p.iters()
+    ct, at = p.trace(nb_iter)
+    B = len(iters)
+    segs = panda_segs()
+    rel, flagged, runs = np.zeros(B), [], {}
+    todo = list(range(B)) if indices is None else [int(i) for i in indices]
+    for i in todo:
+        s = oracle_system_of_instance(cfg, inp, i, segs)
+        u0 = _u_oracle(cfg, inp, inp["U0"][i])
+        r = orc.solve_batch(s, u0, nb_iter, early_stop) if psi is None else orc.solve_batch_cp(s, psi, u0, nb_iter, early_stop)
+        runs[i] = r
+        n = r["iters"]
+        same = int(iters[i]) == n and np.array_equal(at[i][:n], r["trace_alpha"])
+        if same:
+            d = [_rel(float(a), float(b)) for a, b in zip(ct[i][:n], r["trace_cost"])]
+            rel[i] = max(d) if d else 0.0
+        else:
+            rel[i] = np.inf
+        if rel[i] > rtol or i in always:
+            flagged.append(i)
+    results, failures = [], []
+    proofs = {}
+    if flagged:
+        states, ct_ext, at_ext = gpu_states_batch(p, solve, int(max(iters[flagged])))
+        for i in flagged:
+            proofs[i] = prove_instance_batch(cfg, inp, i, psi, states, ct_ext, at_ext, int(iters[i]), early_stop, nb_iter, segs)
+            # the re-runs are the solve under test: same printed costs and step sizes over the iterations it made
+            n = int(iters[i])
+            if not (np.array_equal(ct_ext[i][:n], ct[i][:n], equal_nan=True) and np.array_equal(at_ext[i][:n], at[i][:n], equal_nan=True)):
+                proofs[i]["verdict"] = "unexplained"
+                proofs[i]["steps"].append(dict(it=-1, how="FAIL:re-run differs from the solve"))
+    for i in todo:
+        pf = proofs.get(i)
+        results.append((rel[i] <= rtol, pf))
+        if pf and pf["verdict"] == "unexplained":
+            failures.append(dict(i=i, rel=float(rel[i]), steps=[st for st in pf["steps"] if st["how"].startswith("FAIL") or st.get("stop") == "FAIL"]))
+    summ = summarize(results)
+    summ["n_proven_always"] = sum(1 for i in always if i in proofs and proofs[i]["verdict"] != "unexplained")
+    return summ, rel, failures, runs

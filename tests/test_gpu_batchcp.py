@@ -51,19 +51,23 @@ def test_cp_random_batch_vs_oracle(ctx, cfg_name, B, nb_iter):
     p.solve_batch_cp(psi, nb_iter, False)
     U = p.U()
     ct, at = p.trace(nb_iter)
-    bad = 0
-    for i in range(B):
-        s = oracle_system_of_instance(cfg, inp, i)
-        r = orc.solve_batch_cp(s, psi, inp["U0"][i].reshape(-1), nb_iter, False)
-        same = np.array_equal(at[i], r["trace_alpha"])
-        rel = np.abs(ct[i] - r["trace_cost"]) / np.maximum(np.abs(r["trace_cost"]), 1e-12)
-        if same:
-            assert rel.max() <= 1e-4, f"instance {i}: cost trace rel err {rel.max():.2e}"
-            np.testing.assert_allclose(U[i].reshape(-1), r["u"], rtol=0, atol=1e-4 * max(1.0, np.abs(r["u"]).max()))
-        else:
-            bad += 1
-    assert bad <= max(1, B // 10), f"{bad} of {B} instances took a different alpha path"
+    _gate(p, cfg, inp, psi, nb_iter, False, U, ct, at)
     p.close()
+
+
+def _gate(p, cfg, inp, psi, nb_iter, early_stop, U, ct, at, rtol=1e-4):
+    """Every instance has the oracle's step-size sequence and costs within 1e-4 of the oracle's end-to-end run (then its controls are
+    compared too), or each of its iterations is reproduced by the oracle from the GPU's own controls (tests/parity_proof.py): no
+    instance is skipped and no share of the batch excused."""
+    from tests import parity_proof as pp
+
+    summ, rel, failures, runs = pp.check_batch_solver(p, cfg, inp, psi, nb_iter, early_stop, lambda q, n, es: q.solve_batch_cp(psi, n, es))
+    print(f"parity {summ}")
+    assert not failures, f"{len(failures)} instance(s) neither within {rtol} nor proven: {failures[:3]}"
+    for i, r in runs.items():
+        if rel[i] <= rtol:
+            np.testing.assert_allclose(U[i].reshape(-1), r["u"], rtol=0, atol=1e-4 * max(1.0, np.abs(r["u"]).max()))
+    return summ
 
 
 @pytest.mark.parametrize("cfg_name,B,nb_iter", [("C5", 70, 5), ("C4cp", 20, 4)])
@@ -102,14 +106,12 @@ def test_cp_on_a_sequence_ignores_limits(ctx):
     p.solve_batch_cp(psi, nb_iter, False)
     ct, at = p.trace(nb_iter)
     U = p.U()
+    _gate(p, cfg, inp, psi, nb_iter, False, U, ct, at)
     p.close()
     for i in range(B):
         s = oracle_system_of_instance(cfg, inp, i)
-        r = orc.solve_batch_cp(s, psi, inp["U0"][i].reshape(-1), nb_iter, False)
+        r = orc.solve_batch_cp(s, psi, inp["U0"][i].reshape(-1), 1, False)
         np.testing.assert_allclose(ct[i][0], r["trace_cost"][0], rtol=1e-12)
-        if np.array_equal(at[i], r["trace_alpha"]):
-            np.testing.assert_allclose(ct[i], r["trace_cost"], rtol=1e-4)
-            np.testing.assert_allclose(U[i].reshape(-1), r["u"], rtol=0, atol=1e-4 * max(1.0, np.abs(r["u"]).max()))
     desc.limit_multiplicity = 1
     p = workloads.load_batch(ctx, desc, inp, B)
     p.solve_batch_cp(psi, 1, False)
@@ -133,18 +135,12 @@ def test_cp_time_system_basis_up_to_32_columns(ctx, cfg_name, T, K):
     p.solve_batch_cp(psi, nb_iter, False)
     ct, at = p.trace(nb_iter)
     U = p.U()
-    p.close()
-    bad = 0
-    for i in range(B):
+    for i in range(B):  # one step: rounding only
         s = oracle_system_of_instance(cfg, inp, i)
-        r = orc.solve_batch_cp(s, psi, inp["U0"][i].reshape(-1), nb_iter, False)
+        r = orc.solve_batch_cp(s, psi, inp["U0"][i].reshape(-1), 2, False)
         np.testing.assert_allclose(ct[i][:2], r["trace_cost"][:2], rtol=1e-9)
-        if not np.array_equal(at[i], r["trace_alpha"]):
-            bad += 1
-            continue
-        np.testing.assert_allclose(ct[i], r["trace_cost"], rtol=1e-4)
-        np.testing.assert_allclose(U[i].reshape(-1), r["u"], rtol=0, atol=1e-4 * max(1.0, np.abs(r["u"]).max()))
-    assert bad <= 2
+    _gate(p, cfg, inp, psi, nb_iter, False, U, ct, at)
+    p.close()
 
 
 def test_cp_errors(ctx):

@@ -40,29 +40,34 @@ def test_tutorial_batch_traces_on_gpu(ctx, name, idx):
     p.close()
 
 
-def _compare(p, cfg, inp, B, nb_iter, solve_oracle, tol=1e-6, step_tol=1e-10):
+def _compare(p, cfg, inp, B, nb_iter, psi, tol=1e-6, step_tol=1e-10):
+    """psi = None: BatchILQR.  Every instance has the oracle's step-size sequence and a cost trace within `tol` of the oracle's
+    end-to-end run (then controls and trajectory are compared too) or each of its iterations is reproduced by the oracle from the GPU's
+    own controls (tests/parity_proof.py: cost to 1e-9, decisions from the oracle's trial costs): no instance is skipped, no share of the
+    batch excused (round 2 let B / 8 instances with another step-size sequence go unchecked)."""
+    from tests import parity_proof as pp
+
     U, X = p.U(), p.X()
     ct, at = p.trace(nb_iter)
     cost = p.cost()
-    bad = 0
+    solve = (lambda q, n, es: q.solve_batch(n, es)) if psi is None else (lambda q, n, es: q.solve_batch_cp(psi, n, es))
+    summ, rel, failures, runs = pp.check_batch_solver(p, cfg, inp, psi, nb_iter, False, solve, rtol=tol)
+    print(f"parity {summ}")
+    assert not failures, f"{len(failures)} instance(s) neither within {tol} nor proven: {failures[:3]}"
     for i in range(B):
+        r = runs[i]
         s = oracle_system_of_instance(cfg, inp, i)
-        r = solve_oracle(s, inp["U0"][i].reshape(-1))
-        if not np.array_equal(at[i], r["trace_alpha"]):
-            bad += 1  # a step size decided by a cost comparison inside the rounding of the two linear solves
-            continue
-        rel = np.abs(ct[i] - r["trace_cost"]) / np.maximum(np.abs(r["trace_cost"]), 1e-12)
-        assert rel.max() <= tol, f"instance {i}: cost trace rel err {rel.max():.2e}"
-        assert rel[1] <= step_tol, f"instance {i}: cost after the first step differs by {rel[1]:.2e}"  # one Gauss-Newton step: rounding only
-        scale = max(1.0, np.abs(r["u"]).max())
-        np.testing.assert_allclose(U[i].reshape(-1), r["u"], rtol=0, atol=tol * scale)
+        if rel[i] <= tol:
+            rl = np.abs(ct[i] - r["trace_cost"]) / np.maximum(np.abs(r["trace_cost"]), 1e-12)
+            assert rl[1] <= step_tol, f"instance {i}: cost after the first step differs by {rl[1]:.2e}"  # one Gauss-Newton step: rounding only
+            scale = max(1.0, np.abs(r["u"]).max())
+            np.testing.assert_allclose(U[i].reshape(-1), r["u"], rtol=0, atol=tol * scale)
         # the returned controls rolled out by the oracle's dynamics give the returned trajectory
         x = np.asarray(X[i][0])
         for k in range(cfg["T"] - 1):
             x = orc.step(s, x, U[i][k])[0]
         np.testing.assert_allclose(X[i][-1], x, rtol=0, atol=1e-9 * max(1.0, np.abs(x).max()))
         assert np.isfinite(cost[i])
-    assert bad <= max(1, B // 8), f"{bad} of {B} instances took a different alpha path"
 
 
 @pytest.mark.parametrize("cfg_name,T,limits,u0_scale,tol", [("C2", 30, "inactive", 0.0, 1e-6), ("C3r", 24, "urdf", 0.3, 1e-6), ("C2nd", 20, "inactive", 0.5, 1e-6),
@@ -82,7 +87,7 @@ def test_batch_ilqr_random_batch_vs_oracle(ctx, cfg_name, T, limits, u0_scale, t
     inp["U0"] = inp["U0"] + u0_scale * rng.standard_normal(inp["U0"].shape)
     p = workloads.load_batch(ctx, desc, inp, B)
     p.solve_batch(nb_iter, False)
-    _compare(p, cfg, inp, B, nb_iter, lambda s, u0: orc.solve_batch(s, u0, nb_iter, False), tol=tol)
+    _compare(p, cfg, inp, B, nb_iter, None, tol=tol)
     p.close()
 
 
@@ -102,7 +107,7 @@ def test_wide_basis_cp_vs_oracle(ctx, cfg_name, T, basis, K, u0_scale):
     p.solve_batch_cp(psi, nb_iter, False)
     # overlapping bases make H ill-conditioned (cond(PSI'PSI) ~ 5e2 on top of R = 1e-5): the two linear solves agree to ~1e-6 in
     # cost after a few iterations, inside the 1e-4 the north star asks of final costs
-    _compare(p, cfg, inp, B, nb_iter, lambda s, u0: orc.solve_batch_cp(s, psi, u0, nb_iter, False), tol=1e-4, step_tol=1e-8)
+    _compare(p, cfg, inp, B, nb_iter, psi, tol=1e-4, step_tol=1e-8)
     p.close()
 
 

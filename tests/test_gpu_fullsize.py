@@ -7,8 +7,8 @@ minutes: size-independent properties plus a sample of instances against the orac
   wave or the workgroup an instance lands in);
 * the returned trajectory is the rollout of the returned controls (oracle dynamics), and for the recursive solver the returned
   cost is the reference's cost of that trajectory (oracle cost function);
-* a seeded sample of instances agrees with the oracle in final cost within the north star's 1e-4 (median 1e-6) or -- Riccati
-  solvers -- is proven iteration by iteration (tests/parity_proof.py): no share of the sample is excused."""
+* a seeded sample of instances agrees with the oracle in final cost within the north star's 1e-4 (median 1e-6) or is proven
+  iteration by iteration (tests/parity_proof.py; Riccati and batch solvers alike): no share of the sample is excused."""
 import numpy as np
 import pytest
 
@@ -73,7 +73,7 @@ def test_full_size_properties(ctx, cfg_name, B, nb_iter, solver):
     idx = np.sort(rng.choice(B, 61, replace=False))  # ragged: not a multiple of the wave size
     desc_s, _ = workloads.make_batch(ctx, cfg, B=len(idx))
     inp_s = _take(inp, idx)
-    small = _solve(ctx, cfg, desc_s, inp_s, len(idx), nb_iter, solver, keep=solver in ("al", "recursive"))
+    small = _solve(ctx, cfg, desc_s, inp_s, len(idx), nb_iter, solver, keep=True)
     np.testing.assert_array_equal(small["cost"], big["cost"][idx])
     np.testing.assert_array_equal(small["U"], big["U"][idx])
     np.testing.assert_array_equal(small["X"], big["X"][idx])
@@ -119,5 +119,14 @@ def test_full_size_properties(ctx, cfg_name, B, nb_iter, solver):
         small["p"].close()
         print(f"parity {cfg_name} full size: {summ}")
         assert not failures, f"{len(failures)} instance(s) neither within 1e-4 nor proven: {failures[:3]}"
-    else:  # batch solvers: Gauss-Newton with backtracking on the true cost, compared end to end
-        assert (rel <= 1e-4).mean() >= 0.85, f"{(rel > 1e-4).sum()} of {len(rel)} sampled instances outside 1e-4 (max {rel.max():.2e})"
+    else:  # batch solvers: the same gate on the cut-out -- within 1e-4 of the oracle's end-to-end run with its step-size sequence, or every
+        # iteration reproduced by the oracle from the GPU's own controls (round 2 asked 85 % of the sample to be within 1e-4)
+        from tests import parity_proof as pp
+
+        psi = None if solver == "batch" else psi_of(cfg["psi"], T, 7)
+        solve = (lambda q, n, es: q.solve_batch(n, es)) if solver == "batch" else (lambda q, n, es: q.solve_batch_cp(psi, n, es))
+        sub = list(range(3)) if solver == "batch" else None  # the dense 693-column restatement takes ~10 s per instance
+        summ, _, failures, _ = pp.check_batch_solver(small["p"], cfg, inp_s, psi, nb_iter, False, solve, always=(0, 1), indices=sub)
+        small["p"].close()
+        print(f"parity {cfg_name} full size: {summ}")
+        assert not failures, f"{len(failures)} instance(s) neither within 1e-4 nor proven: {failures[:3]}"

@@ -33,6 +33,9 @@ class OracleProblem:
     def U(self):
         return np.stack([r["U"] for r in self.res])
 
+    def X(self):
+        return np.stack([r["X"] for r in self.res])
+
     def lam(self):
         return np.stack([r["lam"] for r in self.res])
 
@@ -105,3 +108,66 @@ def test_probe_records_the_decisions():
             assert pr["cost0"] == prev
         prev = pr["cost"][-1]
         assert (pr["clamp_margin"] < np.inf) == ((it + 1) % al["lag"] == 0)
+
+
+class OracleBatchProblem:
+    """capi.BatchProblem stand-in for parity_proof.check_batch_solver: BatchILQRCP solves by the oracle (test double, CPU)."""
+
+    def __init__(self, cfg, inp, B, psi):
+        from tests.helpers import oracle_system_of_instance
+
+        self.cfg, self.inp, self.B, self.psi = cfg, inp, B, psi
+        self.sys = [oracle_system_of_instance(cfg, inp, i) for i in range(B)]
+        self.res = None
+
+    def solve(self, nb_iter, early_stop):
+        from tests.helpers import orc
+
+        self.res = [orc.solve_batch_cp(self.sys[i], self.psi, self.inp["U0"][i].reshape(-1), nb_iter, early_stop) for i in range(self.B)]
+
+    def iters(self):
+        return np.array([r["iters"] for r in self.res], dtype=np.int32)
+
+    def U(self):
+        return np.stack([r["u"].reshape(self.inp["U0"][0].shape) for r in self.res])
+
+    def trace(self, nb_iter):
+        ct, at = np.full((self.B, nb_iter), np.nan), np.full((self.B, nb_iter), np.nan)
+        for i, r in enumerate(self.res):
+            ct[i, : r["iters"]], at[i, : r["iters"]] = r["trace_cost"], r["trace_alpha"]
+        return ct, at
+
+
+@pytest.mark.parametrize("name,T,early_stop", [("C5", 60, True), ("C4cp", 30, False)])
+def test_batch_solver_replay_and_gate(name, T, early_stop):
+    """The batch solvers' proof: one oracle iteration from the controls after `it` iterations is iteration `it` of the uninterrupted
+    solve (the solver keeps no other state), and planted faults -- a printed cost off by 1e-6, another step size, a NaN, a missed
+    early stop -- are reported as unexplained."""
+    from tests.helpers import psi_of
+
+    cfg = dict(workloads.config(name), T=T)
+    B, nb_iter = 2, 8
+    desc, inp = workloads.make_batch(OracleFK(), cfg, B=B)
+    psi = psi_of(cfg["psi"], T, 7 + (1 if cfg["kind"] == 1 else 0))
+    p = OracleBatchProblem(cfg, inp, B, psi)
+    solve = lambda q, n, es: q.solve(n, es)
+    p.solve(nb_iter, early_stop)
+    summ, rel, failures, _ = pp.check_batch_solver(p, cfg, inp, psi, nb_iter, early_stop, solve, always=tuple(range(B)))
+    assert not failures and summ["frac_unexplained"] == 0.0 and np.all(rel == 0.0), (summ, failures)
+    p.solve(nb_iter, early_stop)
+    iters = p.iters()
+    states, ct_ext, at_ext = pp.gpu_states_batch(p, solve, int(iters.max()))
+    pf = pp.prove_instance_batch(cfg, inp, 0, psi, states, ct_ext, at_ext, int(iters[0]), early_stop, nb_iter)
+    assert pf["verdict"] == "stepwise" and all(st["rel"] == 0.0 and st["cost0_rel"] == 0.0 for st in pf["steps"]), pf
+    it = min(2, int(iters[0]) - 1)
+    bad = ct_ext.copy()
+    bad[0, it] *= 1 + 1e-6
+    assert pp.prove_instance_batch(cfg, inp, 0, psi, states, bad, at_ext, int(iters[0]), early_stop, nb_iter)["verdict"] == "unexplained"
+    bad_a = at_ext.copy()
+    bad_a[0, it] = at_ext[0, it] / 2 if at_ext[0, it] > 2e-3 else at_ext[0, it] * 2
+    assert pp.prove_instance_batch(cfg, inp, 0, psi, states, ct_ext, bad_a, int(iters[0]), early_stop, nb_iter)["verdict"] == "unexplained"
+    bad_n = ct_ext.copy()
+    bad_n[0, it + 1] = np.nan
+    assert pp.prove_instance_batch(cfg, inp, 0, psi, states, bad_n, at_ext, int(iters[0]), early_stop, nb_iter)["verdict"] == "unexplained"
+    if early_stop and iters[0] < nb_iter:  # a solve that went on although the stop test had fired
+        assert pp.prove_instance_batch(cfg, inp, 0, psi, states, ct_ext, at_ext, int(iters[0]) + 1, early_stop, nb_iter)["verdict"] == "unexplained"
