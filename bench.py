@@ -297,7 +297,7 @@ def parity_report(ctx, cfg, desc, inp, B, nb_iter, oracle_res):
                    "one oracle iteration from the GPU's own state: the GPU's trajectory handed over, the GPU's accept / reject decisions following "
                    "from the ORACLE's cost of every step size, the cost at the GPU's step size equal to 1e-9 (stepwise), up to comparisons decided "
                    "inside 1e-9 of the oracle's own cost0 (tie; n_tie_decisions) and steps whose deviation the oracle's own neutral variants "
-                   "reproduce or exceed (n_steps_ill_conditioned, worst_ill_ratio = deviation / variant sensitivity <= 1).  "
+                   "reproduce or exceed (n_steps_ill_conditioned, worst_ill_ratio = deviation / largest variant sensitivity, gate <= 4).  "
                    "oracle_self_consistency = the oracle against its own neutral variants end to end: the share within 1e-4 there is what the "
                    "reference's expanding, discontinuous map allows ANY second implementation on this non-converged workload; "
                    "converged = the same instances run to the reference's own stopping test")

@@ -768,6 +768,13 @@ Mat System::cost_xx(const Vec& xk, const Vec&, int k) {  // :286-308
 
 bool System::builtin() const {
     if (!builtinType()) return false;
+    // the simulator is the reference's main extension point (SimulationInterface.h:20): only the simulators of this mirror, exactly, are
+    // lowered; a Cartesian system additionally needs a chain the device can hold.  Everything else runs over the virtuals.
+    if (r) {
+        if (!r->builtinSim()) return false;
+        ilqr_problem_desc tmp;
+        if (kind_ != ILQR_SYS_JOINT && kind_ != ILQR_SYS_JOINT_TIME && !r->lowerChain(&tmp)) return false;
+    }
     for (auto& k : keypoints) {
         const std::type_info& t = typeid(*k);
         if (!(t == typeid(PosOrnKeypoint) || t == typeid(PosOrnKeypointDistFunct) || t == typeid(AngularKeypoint) || t == typeid(AngularTimeKeypoint) ||

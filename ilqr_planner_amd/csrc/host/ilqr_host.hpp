@@ -86,6 +86,10 @@ public:
     virtual void setConfiguration(const Vec& q, const Vec& dq, bool reset_time = true);
     // lowering hook: fill the chain part of the descriptor; false if this simulator cannot run on the device
     virtual bool lowerChain(ilqr_problem_desc*) const { return false; }
+    // Is this object EXACTLY one of the simulators of this header (and, for a wrapper, is the wrapped one)?  A user subclass -- also one of
+    // sim::KDLRobot that overrides the kinematics or the integrator -- inherits lowerChain() but not this: the device would solve it with
+    // the base class's chain and dynamics, so the solvers take such a simulator over its virtuals instead (System::builtin()).
+    virtual bool builtinSim() const { return false; }
     // object frame this simulator reports poses in (TransformedSimulationInterface): row-major R[9], p[3]; false = base frame
     virtual bool frame(double*, double*) const { return false; }
 
@@ -107,6 +111,7 @@ public:
         : KDLRobot(urdf, baseFrame, tipFrame, q, dq, transform_rpy, transform_xyz, true) {}
     void updateKinematics() override;  // one-configuration call of ilqr_fk_batch (the FK kernel), then dx = Jt dq, w = Jr dq
     bool lowerChain(ilqr_problem_desc* d) const override;
+    bool builtinSim() const override { return typeid(*this) == typeid(KDLRobot); }
     Vec jointLowerLimits() const { return lower_; }
     Vec jointUpperLimits() const { return upper_; }
 
@@ -122,6 +127,7 @@ public:
     Vec fkine(const Vec& q);
     Vec fkine() { return fkine(q); }
     void updateKinematics() override;
+    bool builtinSim() const override { return typeid(*this) == typeid(Robot2D); }
 
 protected:
     Vec lengths_;
@@ -144,6 +150,7 @@ public:
     void setConfiguration(const Vec& q, const Vec& dq, bool reset_time = true) override;
     void setTime(double time) override;
     bool lowerChain(ilqr_problem_desc* d) const override { return r_->lowerChain(d); }
+    bool builtinSim() const override { return typeid(*this) == typeid(TransformedSimulationInterface) && r_ && r_->builtinSim(); }
     bool frame(double* R, double* p) const override;
 
 protected:

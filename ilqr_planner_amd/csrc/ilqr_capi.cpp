@@ -35,6 +35,7 @@ struct ilqr_ctx {
     std::vector<hipEvent_t> pool;
     std::vector<ilqr_problem*> problems;  // live problems of this context (destroyed with it)
     // split solves (solve_riccati): the two halves of a batch run on their own streams, joined to `stream` by events
+    int n_simd = 1024;  // SIMDs of the device (4 per CU)
     hipStream_t half_stream[2] = {nullptr, nullptr};
     hipEvent_t ev_begin = nullptr, ev_half_done[2] = {nullptr, nullptr}, ev_stagger = nullptr;
 };
@@ -122,6 +123,7 @@ extern "C" int ilqr_ctx_create(int device_id, ilqr_ctx** out) {
         return 5;
     }
     c->stream = c->own_stream;
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0) c->n_simd = 4 * cus; }
     *out = c;
     return 0;
 }
@@ -353,7 +355,10 @@ extern "C" int ilqr_problem_create(ilqr_ctx* c, const ilqr_problem_desc* d, int 
     int rc = 0;
     rc |= dalloc(p, &p->ddesc, 1);
     double *q0, *dq0, *U0, *tg;
-    for (int i = 0; i < 2; i++) { rc |= dalloc(p, &b.X[i], (size_t)T * NX * Bp); rc |= dalloc(p, &b.U[i], (size_t)(T - 1) * NU * Bp); }
+    // the two buffers of X (of U) are the halves of ONE allocation, U padded to T rows: for n_x = n_u the two pairs have the same stride,
+    // which lets the register-resident sweep address all four with one 32-bit offset per buffer (ilqr_kernels_dpp.hip)
+    rc |= dalloc(p, &b.X[0], (size_t)2 * T * NX * Bp); b.X[1] = b.X[0] + (size_t)T * NX * Bp;
+    rc |= dalloc(p, &b.U[0], (size_t)2 * T * NU * Bp); b.U[1] = b.U[0] + (size_t)T * NU * Bp;
     rc |= dalloc(p, &U0, (size_t)(T - 1) * NU * Bp);
     rc |= dalloc(p, &b.KD, (size_t)(T - 1) * Bp * NU * kd_rowp(NX));
     rc |= dalloc(p, &q0, (size_t)DOF * Bp);
@@ -577,9 +582,14 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
     const bool coop = (path != 1) && n_alpha <= 16;            // all step sizes at once (16 lanes / rows per instance)
     const bool fwd_wave = coop && forward_wave_supported(kind, nd, n_alpha);  // PosOrn-1 / JointSpace-1: linear line search, 32 lanes per instance
     const bool fwd_lin = coop && !fwd_wave && forward_lin_supported(kind, nd, n_alpha);  // PosOrn-2: linear line search, 8 lanes per instance
-    const bool bwd_si = (path != 1) && backward_si_supported(kind, nd, al, p->bufs.m, p->bufs.per_step, p->con_state_only);
+    // the register-resident sweep addresses x, u and the multipliers with 32-bit byte offsets (ilqr_kernels_dpp.hip): batches whose arrays pass
+    // 4 GiB (T * Bp beyond ~38 M) take the other sweeps
+    const bool off32 = (size_t)2 * p->T * p->dims.n_x * p->Bp * 8 < ((size_t)1 << 32) && (size_t)p->T * (p->bufs.m > 0 ? p->bufs.m : 1) * p->Bp * 8 < ((size_t)1 << 32);
+    const bool bwd_si = (path != 1) && off32 && backward_si_supported(kind, nd, al, p->bufs.m, p->bufs.per_step, p->con_state_only);
     const bool bwd_mfma = (path != 1) && !bwd_si && backward_mfma_supported(kind, nd, al, p->bufs.m);  // wave per instance, f64 matrix cores
-    const bool fused = bwd_si && fwd_wave;  // the sweep applies the previous line search's winner itself (ilqr_kernels_coop.hip)
+    bool uniform_R = true;
+    for (int i = 1; i < p->dims.n_u; i++) uniform_R = uniform_R && (p->desc.R_diag[i] == p->desc.R_diag[0]);
+    const bool fused = bwd_si && fwd_wave;  // the sweep applies the previous line search's winner itself (ilqr_kernels_dpp.hip)
 
     // ---- one or two independent halves ("lanes" of the launch schedule).  Instances never interact, so the halves of a large batch are
     // two complete solves on two streams; the second one starts one sweep later, so that its latency-bound sweep runs under the other
@@ -654,7 +664,10 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
                     launch_solver(kind, nd, KER_KP_DERIVS, al, bf, B, st, fi);
                 }
                 ProfScope ps(c, ILQR_PROF_BACKWARD);
-                if (bwd_si) launch_backward_si_coop(al, fused, bf, B, st, sw);
+                // rows in registers, DPP broadcasts (ilqr_kernels_dpp.hip): 16 lanes per instance while that gives every SIMD at most one wave
+                // (the launch is then bound by one wave's instruction stream, which is shorter with 4 instances per wave), 8 lanes per
+                // instance beyond (half the instructions per instance).  Measured crossover between 4096 and 8192 instances on 1024 SIMDs.
+                if (bwd_si) launch_backward_si_dpp(al, fused, uniform_R, (B + 3) / 4 <= c->n_simd ? 16 : 8, bf, B, st, sw);
                 else if (bwd_mfma) launch_backward_mfma(kind, nd, al, bf, B, st);
                 else launch_solver(kind, nd, KER_BACKWARD, al, bf, B, st, fi);
             }

@@ -53,7 +53,7 @@ struct FwdArgs {
     int n_alpha;  // number of step sizes 1, 1/2, ... the line search may try (11 for alpha_floor = 1e-3)
     double penalty_roll, penalty_update;
     int kp_ext;   // some keypoint has a dead zone, an object frame or its own control penalty (selects the full keypoint code)
-    int fused;    // the acceptance of the line search is applied by the next sweep (k_backward_si_coop<.., true>): until then the accepted
+    int fused;    // the acceptance of the line search is applied by the next sweep (k_backward_si_dpp<.., true>): until then the accepted
                   // trajectory of an instance with pend > 0 is xbar + alpha (x(1) - xbar) over its two buffers
 };
 
@@ -74,7 +74,7 @@ enum { KER_INIT = 0, KER_BACKWARD = 1, KER_FORWARD = 2, KER_FWD_SPEC = 3, KER_FW
 void launch_solver(int kind, int nd, int which, bool al, const Bufs& a, int B, hipStream_t st, const FwdArgs& f);
 bool backward_si_supported(int kind, int nd, bool al, int m, int per_step, bool con_state_only);
 void launch_solver_v2(int kind, int nd, int which, bool al, const Bufs& a, int B, int T, hipStream_t st, const FwdArgs& f);
-void launch_backward_si_coop(bool al, bool fused, const Bufs& a, int B, hipStream_t st, const SweepArgs& sw);
+void launch_backward_si_dpp(bool al, bool fused, bool uniform_R, int lpi, const Bufs& a, int B, hipStream_t st, const SweepArgs& sw);  // rows in registers, DPP broadcasts (ilqr_kernels_dpp.hip)
 bool backward_mfma_supported(int kind, int nd, bool al, int m);
 int backward_ws_entries(int kind, int nd);  // doubles per instance of k_backward's workspace
 void launch_backward_mfma(int kind, int nd, bool al, const Bufs& a, int B, hipStream_t st);  // needs KER_KP_DERIVS first

@@ -186,7 +186,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         LDS_ORDER();
     }
 
-    // ---- prefetch ring: x, u (and lambda, I for AL); every load unconditional (see ilqr_kernels_coop.hip)
+    // ---- prefetch ring: x, u (and lambda, I for AL); every load unconditional (see ilqr_kernels_dpp.hip)
     constexpr int PF = 3;
     const size_t Xstep = (size_t)NX * Bp, Ustep = (size_t)NU * Bp, Lstep = (size_t)m * Bp;
     const int lr_ = (AL && l < m) ? l : 0;
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         {
             double sv = s0;
             UNR for (int c = 0; c < NU; c++) {
-                // ONE expression for all entries (see k_backward_si_coop): the entries of the pivot row / column read the constant -1 for "their"
+                // ONE expression for all entries (as the single-integrator sweep did while it kept its matrices in LDS): the entries of the pivot row / column read the constant -1 for "their"
                 // a_ic / a_cj and take 0 for their own value, which turns  s - (a_ic r) a_cj  into  a_ic r  (column c),  a_cj r  (row c) and
                 // -r  (the pivot) with the bits of the direct expressions -- instead of three selects per pivot.  The -1 sits on the diagonal
                 // of sS for good: the diagonal entries live in sD (written there by their lanes, read from there as the pivot and, below, as
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 const double acj = sS[c][qj];
                 const double acc = sD[c];
                 LDS_ORDER();
-                const double r = rcp_nr_m(acc);  // (forming the next pivot's reciprocal early, as k_backward_si_coop does, costs three more broadcast reads
+                const double r = rcp_nr_m(acc);  // (forming the next pivot's reciprocal early, as the LDS-resident single-integrator sweep does, costs three more broadcast reads
                                                  // per pivot here and measured 3 % slower)
                 const double tt = aic * r;
                 const double val = fma(-tt, acj, sv * pvm[c]);

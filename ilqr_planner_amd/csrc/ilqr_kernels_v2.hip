@@ -106,7 +106,7 @@ static void launch_al_post(const Bufs& a, int B, int T, hipStream_t st, const Fw
     hipLaunchKernelGGL((k_al_post<S>), dim3((B + 255) / 256, T - 1), dim3(256), 0, st, a, f);
 }
 
-// closed-form sweep (k_backward_si_coop): usable for single-integrator dynamics when no constraint row touches the controls, the rows
+// closed-form sweep (k_backward_si_dpp): usable for single-integrator dynamics when no constraint row touches the controls, the rows
 // are shared over k and there are at most 4 of them (they live in registers)
 bool backward_si_supported(int kind, int nd, bool al, int m, int per_step, bool con_state_only) {
     if (!((kind == 0 || kind == 2) && nd == 1)) return false;  // PosOrn-1 and JointSpace-1

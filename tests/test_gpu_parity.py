@@ -332,7 +332,7 @@ def test_warm_start_and_tracking(ctx):
     # warm start without shift: a 0-iteration solve re-rolls the accepted controls and reproduces the cost
     p.warm_start(0)
     p.solve_recursive(0, True, False)
-    np.testing.assert_allclose(p.cost(), cost, rtol=1e-12)
+    np.testing.assert_allclose(p.cost(), cost, rtol=1e-11)  # (the re-rolled trajectory differs from the blended one by rounding)
     np.testing.assert_allclose(p.U(), U, rtol=0, atol=0)
     Xr = p.X()  # the re-rolled trajectory (equal to X up to rounding: X came out of the line-search blend)
     np.testing.assert_allclose(Xr, X, rtol=0, atol=1e-12)
