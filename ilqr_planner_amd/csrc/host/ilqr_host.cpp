@@ -1637,6 +1637,8 @@ BatchResult AL_ILQR::solveBatch(const BatchInputs& in, int nb_iter, int lag, dou
 
 std::tuple<std::vector<Vec>, std::vector<Vec>, std::vector<Vec>> AL_ILQR::solve(const std::vector<Vec>& U0, int nb_iter, int lag, double penalty, double scaling,
                                                                               bool line_search, bool early_stop, CallBackMessage* cb) {  // AL-ILQR.cpp:50-232
+    if (!s->builtin())  // user-defined System / Keypoint / SimulationInterface: the same algorithm over its virtuals
+        return solve_al_over_virtuals(*s, inequality, multipliers, U0, nb_iter, lag, penalty, scaling, line_search, early_stop, cb);
     BatchInputs in;
     in.B = 1;
     in.U0 = flatten(U0, s->getHorizon(), s->getNbCtrlVar());

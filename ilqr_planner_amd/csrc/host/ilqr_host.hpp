@@ -476,6 +476,11 @@ struct Constraint {  // AL-ILQR.h:20-23
 std::tuple<std::vector<Vec>, std::vector<Vec>, std::vector<Vec>, std::vector<Mat>, std::vector<Vec>, double> solve_over_virtuals(
     sys::System& s, const std::vector<Vec>& U0, int nb_iter, bool line_search, bool early_stop, CallBackMessage* cb);
 
+// AL_ILQR over the same interface (multipliers updated in place, as the reference's member is)
+std::tuple<std::vector<Vec>, std::vector<Vec>, std::vector<Vec>> solve_al_over_virtuals(sys::System& s, const std::vector<Constraint>& inequality, std::vector<Vec>& multipliers,
+                                                                                        const std::vector<Vec>& U0, int nb_iter, int lag_update_step, double penalty,
+                                                                                        double scaling_factor, bool line_search, bool early_stop, CallBackMessage* cb);
+
 class ILQRRecursive {  // ILQRRecursive.h:21-42
 public:
     explicit ILQRRecursive(const std::shared_ptr<sys::System>& s) : s(s) {}

@@ -1,4 +1,5 @@
-// ilqr_host_loop.cpp -- ILQRRecursive over the virtual System interface, for USER-DEFINED System / Keypoint subclasses only.
+// ilqr_host_loop.cpp -- ILQRRecursive and AL_ILQR over the virtual System interface, for USER-DEFINED System / Keypoint / SimulationInterface
+// subclasses only.
 //
 // SURVEY.md section 8(b), last bullet: the reference's solver is written against the virtuals of sys::System (forwardPass, cost, cost_x,
 // cost_xx, cost_F*; ILQRRecursive.cpp:21-181), so a C++ user may hand it a System of their own.  Such a system has no lowering to the
@@ -9,6 +10,7 @@
 // planner systems, sequences of them, the built-in keypoints) is lowered and solved on the GPU, and fails loudly when that is not possible;
 // ILQRRecursive::solve chooses by the TYPE of the system (System::builtin()), never by whether a device call succeeded.  Nothing under
 // oracle/ is used here or anywhere else in the product.
+#include <chrono>
 #include <cmath>
 #include <iostream>
 #include <sstream>
@@ -113,23 +115,55 @@ std::string num(double v) {
 
 }  // namespace
 
-// ILQRRecursive::solve (ILQRRecursive.cpp:21-181) over the virtual interface of `s`.
-std::tuple<std::vector<Vec>, std::vector<Vec>, std::vector<Vec>, std::vector<Mat>, std::vector<Vec>, double> solve_over_virtuals(
-    sys::System& s, const std::vector<Vec>& U0, int nb_iter, bool line_search, bool early_stop, CallBackMessage* cb) {
+// ILQRRecursive::solve (ILQRRecursive.cpp:21-181) and AL_ILQR::solve (AL-ILQR.cpp:50-232) over the virtual interface of `s`, with the
+// reference's ORDER of calls into the system (a user's System may be stateful -- a simulator advanced by forwardPass): reset() at the top
+// of the recursive solve (:29) but not of the AL one, reset() at the top of every iteration before cost_F_xx (:66 / AL :92), and in the
+// line search reset(), getFxJac(), then per step forwardPass BEFORE cost (:131-147 / AL :165-185).  con == nullptr: plain recursive.
+namespace {
+struct ALState {
+    const std::vector<Constraint>* con;
+    std::vector<Vec>* lambda;
+    int lag;
+    double penalty, scaling;
+};
+
+// AL_ILQR::constraints (AL-ILQR.cpp:21-44): g = A [x; u] - b, I = diag(g < 0 && lambda == 0 ? 0 : 1); an empty constraint gives zeros
+void constraints_of(const ALState& al, const Vec& x, const Vec& u, int k, double pen, Vec& I_out, Vec& g_out) {
+    const Constraint& c = al.con->at(k);
+    const int m = (int)c.b.size();
+    I_out.assign(m, 0.0);
+    g_out.assign(m, 0.0);
+    if (m == 0) return;
+    const int nx = (int)x.size(), ns = nx + (int)u.size();
+    if (c.A.rows != m || c.A.cols != ns) throw std::runtime_error("[AL_ILQR] constraint A must be m x (nb_state_var + nb_ctrl_var)");
+    for (int r = 0; r < m; r++) {
+        double g = 0;
+        for (int j = 0; j < ns; j++) g += c.A(r, j) * (j < nx ? x[j] : u[j - nx]);
+        g -= c.b[r];
+        g_out[r] = g;
+        I_out[r] = pen * ((g < 0 && al.lambda->at(k)[r] == 0) ? 0.0 : 1.0);
+    }
+}
+
+std::tuple<std::vector<Vec>, std::vector<Vec>, std::vector<Vec>, std::vector<Mat>, std::vector<Vec>, double> riccati_over_virtuals(
+    sys::System& s, const std::vector<Vec>& U0, int nb_iter, bool line_search, bool early_stop, CallBackMessage* cb, ALState* al) {
     const int T = s.getHorizon(), nu = s.getNbCtrlVar();
     if ((int)U0.size() != T - 1) throw std::runtime_error("[solver] U0 must hold horizon-1 control vectors");
     for (auto& u : U0)
         if ((int)u.size() != nu) throw std::runtime_error("[solver] each U0 entry must have nb_ctrl_var entries");
-    const Vec zero_u(nu, 0.0);
-    std::vector<Vec> X(T), fX(T), U = U0, nX(T), nfX(T), nU(T - 1), ds(T - 1);
+    if (al && ((int)al->con->size() < T - 1 || (int)al->lambda->size() < T - 1)) throw std::runtime_error("[AL_ILQR] one constraint and one multiplier vector per control step");
+    std::vector<Vec> X(T), fX(T), U = U0, nX(T), nfX(T), nU(T - 1), ds(T - 1), Is(T - 1), Cs(T - 1);
     std::vector<Mat> As(T - 1), Bs(T - 1), Ks(T - 1);
+    double penalty = al ? al->penalty : 0.0;
 
-    // initial rollout (:41-56)
-    s.reset();
-    X[0] = s.getState();
+    // initial rollout (:41-56 / AL :68-85): cost, then the step
+    if (!al) s.reset();
+    X[0] = s.getInitState();
     fX[0] = std::get<0>(s.getFxJac());
+    if (al) (void)s.getFxJac();  // (AL :66 evaluates it a second time for J)
     double cost0 = 0;
     for (int k = 0; k < T - 1; k++) {
+        if (al) constraints_of(*al, X[k], U[k], k, penalty, Is[k], Cs[k]);
         cost0 += s.cost(X[k], U[k], k)[0];
         auto st = s.forwardPass(X[k], U[k], k);
         X[k + 1] = std::get<0>(st);
@@ -142,18 +176,40 @@ std::tuple<std::vector<Vec>, std::vector<Vec>, std::vector<Vec>, std::vector<Mat
     double alpha = 1;
     int it_done = 0;
     for (int it = 0; it < nb_iter; it++) {
-        // backward pass (:68-97)
+        const auto t_start = std::chrono::steady_clock::now();
+        s.reset();
+        // backward pass (:68-97 / AL :94-145)
         Mat P = s.cost_F_xx(X[T - 1]);
         Vec p = s.cost_F_x(X[T - 1]);
         for (int k = T - 2; k >= 0; k--) {
             const Mat &A = As[k], &B = Bs[k];
+            const int nx = A.rows;
             const Mat BtP = tmul(B, P), AtP = tmul(A, P);
-            const Mat Qux = add(s.cost_ux(X[k], U[k], k), mul(BtP, A));
-            const Mat Quu = add(s.cost_uu(X[k], U[k], k), mul(BtP, B));
-            const Mat Qxx = add(s.cost_xx(X[k], U[k], k), mul(AtP, A));
-            const Mat Qxu = add(s.cost_xu(X[k], U[k], k), mul(AtP, B));
-            const Vec Qu = addv(s.cost_u(X[k], U[k], k), tmulv(B, p));
-            const Vec Qx = addv(s.cost_x(X[k], U[k], k), tmulv(A, p));
+            Mat Qux = add(s.cost_ux(X[k], U[k], k), mul(BtP, A));
+            Mat Quu = add(s.cost_uu(X[k], U[k], k), mul(BtP, B));
+            Mat Qxx = add(s.cost_xx(X[k], U[k], k), mul(AtP, A));
+            Mat Qxu = add(s.cost_xu(X[k], U[k], k), mul(AtP, B));
+            Vec Qu = addv(s.cost_u(X[k], U[k], k), tmulv(B, p));
+            Vec Qx = addv(s.cost_x(X[k], U[k], k), tmulv(A, p));
+            if (al && !Is[k].empty()) {  // c_u' I c_x etc. and c' (lambda + I g)  (AL :124-129)
+                const Mat& Ac = al->con->at(k).A;
+                const Vec& lam = al->lambda->at(k);
+                for (size_t r = 0; r < Is[k].size(); r++) {
+                    const double w = lam[r] + Is[k][r] * Cs[k][r];
+                    for (int i = 0; i < nu; i++) {
+                        const double au = Ac((int)r, nx + i);
+                        for (int j = 0; j < nx; j++) Qux(i, j) += au * Is[k][r] * Ac((int)r, j);
+                        for (int j = 0; j < nu; j++) Quu(i, j) += au * Is[k][r] * Ac((int)r, nx + j);
+                        Qu[i] += au * w;
+                    }
+                    for (int i = 0; i < nx; i++) {
+                        const double ax = Ac((int)r, i);
+                        for (int j = 0; j < nx; j++) Qxx(i, j) += ax * Is[k][r] * Ac((int)r, j);
+                        for (int j = 0; j < nu; j++) Qxu(i, j) += ax * Is[k][r] * Ac((int)r, nx + j);
+                        Qx[i] += ax * w;
+                    }
+                }
+            }
             Mat Qr = Quu;
             for (int i = 0; i < nu; i++) Qr(i, i) += 1e-6;  // the regularisation enters the inverse only (:89)
             Mat Qi = inverse(Qr);
@@ -170,10 +226,11 @@ std::tuple<std::vector<Vec>, std::vector<Vec>, std::vector<Vec>, std::vector<Mat
         alpha = 2;
         double newCost = 0, dun = 0;
         do {
-            alpha /= 2.0;
             s.reset();
-            nX[0] = s.getState();
+            alpha /= 2.0;
+            nX[0] = X[0];
             nfX[0] = std::get<0>(s.getFxJac());
+            if (al) (void)s.getFxJac();
             dun = 0;
             newCost = 0;
             for (int k = 0; k < T - 1; k++) {
@@ -184,22 +241,32 @@ std::tuple<std::vector<Vec>, std::vector<Vec>, std::vector<Vec>, std::vector<Mat
                 for (int i = 0; i < nu; i++) { du[i] += alpha * ds[k][i]; n2 += du[i] * du[i]; }
                 dun += std::sqrt(n2);
                 nU[k] = addv(U[k], du);
-                newCost += s.cost(nX[k], nU[k], k)[0];
-                auto st = s.forwardPass(nX[k], nU[k], k);
+                auto st = s.forwardPass(nX[k], nU[k], k);  // the step first, then the cost (:133-150)
                 nX[k + 1] = std::get<0>(st);
                 nfX[k + 1] = std::get<1>(st);
                 As[k] = std::get<2>(st);
                 Bs[k] = std::get<3>(st);
+                if (al) constraints_of(*al, nX[k], nU[k], k, penalty, Is[k], Cs[k]);
+                newCost += s.cost(nX[k], nU[k], k)[0];
             }
             newCost += s.cost_F(nX[T - 1])[0];
         } while (((newCost >= cost0) || std::isnan(newCost)) && alpha > 1e-3 && line_search);
+        if (al && (it + 1) % al->lag == 0) {  // multiplier update with the UPDATED penalty (AL :202-208)
+            penalty *= al->scaling;
+            for (int k = 0; k < T - 1; k++)
+                for (size_t r = 0; r < al->lambda->at(k).size() && r < Cs[k].size(); r++) {
+                    const double v = al->lambda->at(k)[r] + penalty * Cs[k][r];
+                    al->lambda->at(k)[r] = v > 0 ? v : 0;
+                }
+        }
         cost0 = newCost;
         X = nX; fX = nfX; U = nU;
         it_done = it + 1;
-        const std::string msg = "Iteration " + std::to_string(it + 1) + ", Cost: " + num(cost0) + ", alpha= " + num(alpha);
+        const std::chrono::duration<double> dt = std::chrono::steady_clock::now() - t_start;
+        const std::string msg = "Iteration " + std::to_string(it + 1) + ", Cost: " + num(cost0) + ", alpha= " + num(alpha) + ", time= " + num(dt.count());
         if (cb) cb->notify(msg);
         else std::cout << msg << std::endl;
-        if (early_stop && alpha * std::sqrt(dun) < 1e-3 && cost0 < 1e-3) break;  // (:174)
+        if (early_stop && alpha * std::sqrt(dun) < 1e-3 && (al || cost0 < 1e-3)) break;  // (:174; AL :225 has no cost test)
     }
     s.reset();
     std::vector<Vec> dso = ds;
@@ -207,6 +274,21 @@ std::tuple<std::vector<Vec>, std::vector<Vec>, std::vector<Vec>, std::vector<Mat
         for (auto& e : v) e *= (it_done > 0 ? alpha : 1.0);  // the returned feed-forward terms are scaled by the accepted alpha (:128,144,162)
     if (it_done == 0) { Ks.clear(); dso.clear(); }
     return std::make_tuple(X, fX, U, Ks, dso, cost0);
+}
+}  // namespace
+
+std::tuple<std::vector<Vec>, std::vector<Vec>, std::vector<Vec>, std::vector<Mat>, std::vector<Vec>, double> solve_over_virtuals(
+    sys::System& s, const std::vector<Vec>& U0, int nb_iter, bool line_search, bool early_stop, CallBackMessage* cb) {
+    return riccati_over_virtuals(s, U0, nb_iter, line_search, early_stop, cb, nullptr);
+}
+
+std::tuple<std::vector<Vec>, std::vector<Vec>, std::vector<Vec>> solve_al_over_virtuals(sys::System& s, const std::vector<Constraint>& inequality, std::vector<Vec>& multipliers,
+                                                                                        const std::vector<Vec>& U0, int nb_iter, int lag_update_step, double penalty,
+                                                                                        double scaling_factor, bool line_search, bool early_stop, CallBackMessage* cb) {
+    if (lag_update_step <= 0) throw std::runtime_error("[AL_ILQR] lag_update_step must be positive");
+    ALState al{&inequality, &multipliers, lag_update_step, penalty, scaling_factor};
+    auto r = riccati_over_virtuals(s, U0, nb_iter, line_search, early_stop, cb, &al);
+    return std::make_tuple(std::get<0>(r), std::get<1>(r), std::get<2>(r));
 }
 
 }  // namespace solver

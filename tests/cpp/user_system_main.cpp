@@ -13,6 +13,10 @@ using namespace ilqr_planner;
 struct PointSys : sys::System {
     double dt;
     Vec x, xt, qdiag;
+    // call log of the line search: the reference steps the system BEFORE it asks for the cost of the step (ILQRRecursive.cpp:133-150) and
+    // resets it at the top of every iteration before cost_F_xx (:66)
+    int n_fp = 0, n_cost_before_fp = 0, n_reset = 0, n_Fxx_without_reset = 0;
+    bool stepped_since_cost = true, reset_since_Fxx = true, in_total = false;
     PointSys(int T, double dt_) : sys::System(nullptr, {}, Vec{1e-2, 1e-2}, T, 2, {}), dt(dt_) {
         nb_state_var_ = 4; nb_ctrl_var_ = 2; nb_target_var_ = 4; nb_Q_var_ = 4;
         x0_ = Vec{0.2, -0.1, 0.0, 0.3};
@@ -21,7 +25,7 @@ struct PointSys : sys::System {
         x = x0_;
     }
     Vec getState() override { return x; }
-    void reset() override { x = x0_; }
+    void reset() override { x = x0_; n_reset++; reset_since_Fxx = true; }
     std::tuple<Vec, Mat> getFxJac() override { return std::make_tuple(x, Mat::Identity(4)); }
     StepOut forwardPass(const Vec&, const Vec& u, int) override {  // advances the "simulator" (this object), as the reference's systems do
         Mat A = Mat::Identity(4), B(4, 2);
@@ -33,10 +37,14 @@ struct PointSys : sys::System {
         xn[2] = x[2] + dt * u[0];
         xn[3] = x[3] + dt * u[1];
         x = xn;
+        n_fp++; stepped_since_cost = true;
         return std::make_tuple(x, x, A, B, Mat::Identity(4));
     }
     // the reference's convention: cost = e'Qe + u'Ru, derivatives WITHOUT the factor 2 (cost_x = -J'Qe, cost_xx = J'QJ, cost_u = Ru)
+    Mat cost_F_xx(const Vec& xk) override { if (!reset_since_Fxx) n_Fxx_without_reset++; reset_since_Fxx = false; return sys::System::cost_F_xx(xk); }
     Vec cost(const Vec& xk, const Vec& uk, int k) override {
+        if (!in_total && k > 0 && k < horizon_ - 1 && !stepped_since_cost) n_cost_before_fp++;  // two costs in a row without a step between
+        if (k < horizon_ - 1) stepped_since_cost = false;
         double c = 0;
         if (k == horizon_ - 1)
             for (int i = 0; i < 4; i++) c += qdiag[i] * (xt[i] - xk[i]) * (xt[i] - xk[i]);
@@ -56,6 +64,7 @@ struct PointSys : sys::System {
         return H;
     }
     double total(const std::vector<Vec>& U) {  // independent of the solver: plain rollout
+        in_total = true;
         reset();
         double c = 0;
         for (int k = 0; k < horizon_ - 1; k++) {
@@ -63,13 +72,21 @@ struct PointSys : sys::System {
             forwardPass(x, U[k], k);
         }
         c += cost(x, Vec(2, 0.0), horizon_ - 1)[0];
+        in_total = false; stepped_since_cost = true;
         return c;
     }
 };
 
 struct Collect : CallBackMessage {
-    int n = 0;
-    void notify(const std::string&) override { n++; }
+    int n = 0, with_time = 0;
+    void notify(const std::string& m) override { n++; if (m.find(", time= ") != std::string::npos) with_time++; }
+};
+
+// A user subclass of sim::KDLRobot that changes the kinematics: it inherits lowerChain(), but the device would solve the BASE chain --
+// it must be taken over its virtuals (System::builtin() looks at the exact type of the simulator)
+struct OffsetRobot : sim::KDLRobot {
+    using sim::KDLRobot::KDLRobot;
+    void updateKinematics() override { sim::KDLRobot::updateKinematics(); x[2] += 0.05; }
 };
 
 #define CHECK(cond)                                                    \
@@ -122,6 +139,33 @@ int main() {
         solver_.solveBatch(in, 1, true, false);
     } catch (const std::runtime_error&) { threw = true; }
     CHECK(threw);
+    CHECK(cb.with_time == cb.n);  // "Iteration i, Cost: c, alpha= a, time= t" (ILQRRecursive.cpp:168)
+    CHECK(s->n_cost_before_fp == 0);  // forwardPass before cost in the line search
+    CHECK(s->n_Fxx_without_reset == 0);  // reset() before every backward pass
+    // AL_ILQR over the virtuals (AL-ILQR.cpp:50-232): one row u_0 <= half the largest value the unconstrained optimum takes, multipliers start at 0
+    {
+        double umax = -1e9;
+        for (int k = 0; k < T - 1; k++) umax = std::fmax(umax, U[k][0]);
+        CHECK(umax > 0.05);
+        const double bound = 0.5 * umax;
+        auto s2 = std::make_shared<PointSys>(T, 0.1);
+        solver::Constraint c;
+        c.A = Mat(1, 6);
+        c.A(0, 4) = 1.0;
+        c.b = Vec{bound};
+        std::vector<solver::Constraint> cons(T - 1, c);
+        std::vector<Vec> lam0(T - 1, Vec{0.0});
+        solver::AL_ILQR al(s2, cons, lam0);
+        Collect cb2;
+        auto o = al.solve(U0, 40, 2, 1.0, 2.0, false, false, &cb2);  // full steps: the reference line search judges by the plain cost (AL-ILQR.cpp:193-199), which a step towards the bound raises
+        CHECK(cb2.n == 40 && cb2.with_time == 40);
+        const auto& Ua = std::get<2>(o);
+        double worst = -1e9;
+        for (int k = 0; k < T - 1; k++) worst = std::fmax(worst, Ua[k][0] - bound);
+        std::printf("AL: unconstrained max u0 %.4g, bound %.4g, worst violation %.3g\n", umax, bound, worst);
+        CHECK(worst < 0.05 * umax);   // the unconstrained optimum violates the bound by umax / 2; the augmented-Lagrangian solve respects it
+        CHECK(s2->n_cost_before_fp == 0 && s2->n_Fxx_without_reset == 0);
+    }
     std::printf("ok: cost %.6g -> %.6g in 3 iterations\n", c_init, cost);
     return 0;
 }
