@@ -29,7 +29,7 @@ EXPORTS = [
     "ilqr_problem_get_iters", "ilqr_problem_get_status", "ilqr_problem_get_lambda", "ilqr_problem_get_trace",
     "ilqr_problem_get_X_dev", "ilqr_problem_get_U_dev", "ilqr_problem_get_cost_dev", "ilqr_fk_batch",
     "ilqr_profile_enable", "ilqr_profile_reset", "ilqr_profile_get", "ilqr_chain_from_urdf", "ilqr_urdf_last_error",
-    "ilqr_problem_reset_multipliers", "ilqr_problem_warm_start", "ilqr_problem_track", "ilqr_problem_track_dev", "ilqr_ctx_set_split",
+    "ilqr_problem_reset_multipliers", "ilqr_problem_warm_start", "ilqr_problem_track", "ilqr_problem_track_dev", "ilqr_ctx_set_split", "ilqr_ctx_set_crosscheck",
 ]
 
 
@@ -108,6 +108,7 @@ def load():
     L.ilqr_ctx_set_stream.argtypes = [vp, vp]
     L.ilqr_ctx_synchronize.argtypes = [vp]
     L.ilqr_ctx_set_split.argtypes = [vp, C.c_int]
+    L.ilqr_ctx_set_crosscheck.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.ilqr_problem_create.argtypes = [vp, C.POINTER(ProblemDesc), C.c_int, C.POINTER(vp)]
     L.ilqr_problem_destroy.argtypes = [vp]
     L.ilqr_problem_destroy.restype = None
@@ -259,6 +260,15 @@ class Context:
     def synchronize(self):
         self.check(self.L.ilqr_ctx_synchronize(self.h))
 
+    def set_crosscheck(self, generic_kernels=False, cp_lane_solve=False, cp_general=False):
+        """Cross-check kernel variants (ilqr_ctx_set_crosscheck); context state, in force until changed."""
+        self.check(self.L.ilqr_ctx_set_crosscheck(self.h, int(bool(generic_kernels)), int(bool(cp_lane_solve)), int(bool(cp_general))))
+
+    def crosscheck_from_env(self):
+        """TEST PLUMBING of this Python wrapper (the library itself reads no environment variable): the parity tests select the cross-check
+        variants per test case through ILQR_HIP_PATH=v1, ILQR_CP_SOLVE=lane, ILQR_CP=general; every solve of BatchProblem passes them on."""
+        self.set_crosscheck(os.environ.get("ILQR_HIP_PATH") == "v1", os.environ.get("ILQR_CP_SOLVE") == "lane", os.environ.get("ILQR_CP") == "general")
+
     def set_split(self, on: bool):
         """Two-stream solve of large batches on / off (ilqr_ctx_set_split); off = one kernel at a time, for profiler runs."""
         self.check(self.L.ilqr_ctx_set_split(self.h, int(bool(on))))
@@ -344,14 +354,17 @@ class BatchProblem:
 
     # ---- solvers (asynchronous on the context's stream)
     def solve_recursive(self, nb_iter, line_search=True, early_stop=True):
+        self.ctx.crosscheck_from_env()
         self.ctx.check(self.L.ilqr_solve_recursive(self.h, nb_iter, int(line_search), int(early_stop)))
 
     def solve_al(self, nb_iter, lag_update_step, penalty, scaling_factor, line_search=True, early_stop=True):
+        self.ctx.crosscheck_from_env()
         self.ctx.check(self.L.ilqr_solve_al(self.h, nb_iter, lag_update_step, penalty, scaling_factor, int(line_search), int(early_stop)))
 
     def solve_batch_cp(self, psi, nb_iter, early_stop=True):
         psi = _f64(psi)
         assert psi.shape[0] == (self.T - 1) * self.dims.n_u
+        self.ctx.crosscheck_from_env()
         self.ctx.check(self.L.ilqr_solve_batch_cp(self.h, _dp(psi), psi.shape[1], nb_iter, int(early_stop)))
 
     def solve_batch(self, nb_iter, early_stop=True):

@@ -19,6 +19,8 @@ namespace ilqr_planner {
 
 static ilqr_ctx* g_ctx = nullptr;
 
+// One context per process, created when the first object needs the device.  Device choice, resolved ONCE here:
+// ILQR_DEVICE if set, else LOCAL_RANK (one rank per GPU under torch.distributed.run), else 0.
 ilqr_ctx* device_context() {
     if (!g_ctx) {
         int dev = 0;

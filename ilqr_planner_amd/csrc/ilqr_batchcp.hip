@@ -690,7 +690,7 @@ static int run_cp(BatchCPState& st, const DevDesc& h, Bufs& bufs, int nb_iter, i
     c.psi = st.psi; c.H0 = st.H0; c.Wkp = st.Wkp; c.Ckp = st.Ckp; c.rkp = st.rkp; c.gu = st.gu; c.dw = st.dw; c.dun = st.dun;
     c.Kw = st.Kw; c.early_stop = early_stop; c.n_alpha = 11; c.it = 0;
     c.wref = nullptr;
-    const bool wave_solve = !(std::getenv("ILQR_CP_SOLVE") && !std::strcmp(std::getenv("ILQR_CP_SOLVE"), "lane"));  // cross-check: lane per instance
+    const bool wave_solve = !st.xc_lane_solve;  // cross-check (ilqr_ctx_set_crosscheck): one lane per instance
     ph(ILQR_PROF_ROLLOUT);
     hipLaunchKernelGGL((k_cp_init<S>), dim3((B + 255) / 256), dim3(256), 0, stream, bufs);
     for (int it = 0; it < nb_iter; it++) {
@@ -768,7 +768,7 @@ static int run_cpl(BatchCPState& st, const DevDesc& h, Bufs& bufs, const std::ve
     c.wt = st.wt; c.pp = st.pp; c.wv = st.wv; c.g0 = st.g0; c.c00 = st.c00; c.xbk = st.xbk;
     c.Kw = st.Kw; c.early_stop = early_stop; c.n_alpha = 11; c.it = 0;
     c.wref = st.wref;
-    const bool wave_solve = !(std::getenv("ILQR_CP_SOLVE") && !std::strcmp(std::getenv("ILQR_CP_SOLVE"), "lane"));  // cross-check: lane per instance
+    const bool wave_solve = !st.xc_lane_solve;  // cross-check (ilqr_ctx_set_crosscheck): one lane per instance
     ph(ILQR_PROF_ROLLOUT);   // rollout of u0, its keypoint states and the quadratic forms of the control cost (walks the horizon)
     hipLaunchKernelGGL((k_cpl_states<S>), dim3((B + 255) / 256, DOF), dim3(256), 0, stream, bufs, c);
     hipLaunchKernelGGL((k_cpl_quad<S, KWP>), dim3((B + 15) / 16), dim3(256), 0, stream, bufs, c);
@@ -839,7 +839,7 @@ int batchcp_solve(BatchCPState& st, const DevDesc& h, Bufs& bufs, int nx, int nu
         return 1;
     }
     }  // !same
-    static const bool general = std::getenv("ILQR_CP") && !std::strcmp(std::getenv("ILQR_CP"), "general");  // cross-check path
+    const bool general = st.xc_general;  // cross-check path (ilqr_ctx_set_crosscheck)
     if (KWP == 32) {  // wider bases on the time systems: the same kernels with 32 lanes per instance
         if (h.kind == 3) return run_cp<Sys<3, 1>, 32>(st, h, bufs, nb_iter, early_stop, stream, err, ph);
         if (h.nd == 1) return run_cp<Sys<1, 1>, 32>(st, h, bufs, nb_iter, early_stop, stream, err, ph);

@@ -21,6 +21,7 @@ struct ProfHook {
 // Device buffers of the control-primitive solver; sized for one (problem, Kw) pair and reused across solves.
 struct BatchCPState {
     int KWP = 0, Kw = 0, nkp = 0, nx = 0, Bp = 0, rows = 0;
+    bool xc_lane_solve = false, xc_general = false;  // cross-check variants, set from the context before every solve (ilqr_ctx_set_crosscheck)
     double* psi = nullptr;  // [(T-1) n_u][KWP]   PSI, columns zero-padded to KWP
     double* H0 = nullptr;   // [KWP][KWP]         PSI' R PSI (identity on the padded diagonal)
     double* Wkp = nullptr;  // [n_kp][NX*KWP][Bp] rows of Su PSI at the keypoint steps

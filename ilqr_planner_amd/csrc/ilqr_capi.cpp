@@ -36,6 +36,7 @@ struct ilqr_ctx {
     std::vector<ilqr_problem*> problems;  // live problems of this context (destroyed with it)
     // split solves (solve_riccati): the two halves of a batch run on their own streams, joined to `stream` by events
     int n_simd = 1024;  // SIMDs of the device (4 per CU)
+    bool xc_generic = false, xc_cp_lane = false, xc_cp_general = false;  // cross-check kernel variants (ilqr_ctx_set_crosscheck)
     hipStream_t half_stream[2] = {nullptr, nullptr};
     hipEvent_t ev_begin = nullptr, ev_half_done[2] = {nullptr, nullptr}, ev_stagger = nullptr;
 };
@@ -136,6 +137,7 @@ extern "C" void ilqr_ctx_destroy(ilqr_ctx* c) {
     for (auto& p : c->pending) (void)hipEventDestroy(p.a);
     for (auto e : c->pool) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; i++) {
+        if (c->half_stream[i]) (void)hipStreamSynchronize(c->half_stream[i]);
         if (c->half_stream[i]) (void)hipStreamDestroy(c->half_stream[i]);
         if (c->ev_half_done[i]) (void)hipEventDestroy(c->ev_half_done[i]);
     }
@@ -156,6 +158,14 @@ extern "C" int ilqr_ctx_set_stream(ilqr_ctx* c, void* s) {
 extern "C" int ilqr_ctx_set_split(ilqr_ctx* c, int on) {
     if (!c) return 1;
     c->split = on != 0;
+    return 0;
+}
+
+extern "C" int ilqr_ctx_set_crosscheck(ilqr_ctx* c, int generic_kernels, int cp_lane_solve, int cp_general) {
+    if (!c) return 1;
+    c->xc_generic = generic_kernels != 0;
+    c->xc_cp_lane = cp_lane_solve != 0;
+    c->xc_cp_general = cp_general != 0;
     return 0;
 }
 
@@ -541,13 +551,10 @@ static int ensure_trace(ilqr_problem* p, int nb_iter) {
 }
 
 // Which kernels run an iteration.  Default ("v2"): cooperative kernels -- closed-form single-integrator sweep or the f64-MFMA sweep, all
-// step sizes of the line search in one pass.  ILQR_HIP_PATH=v1 forces the generic lane-per-instance kernels, the cross-check set of
-// the parity tests (also the product path where the cooperative kernels do not apply: joint-space AL rows on the controls, more
-// than 16 AL rows, a second limit set).  This is the library's only environment switch; it is read at every solve.
-static int path_choice() {
-    const char* e = std::getenv("ILQR_HIP_PATH");
-    return (e && !std::strcmp(e, "v1")) ? 1 : 2;
-}
+// step sizes of the line search in one pass.  ilqr_ctx_set_crosscheck(ctx, 1, ..) forces the generic lane-per-instance kernels, the cross-check
+// set of the parity tests (also the product path where the cooperative kernels do not apply: joint-space AL rows on the controls, more
+// than 16 AL rows, a second limit set).  The library reads NO environment variable: the switch is context state.
+static int path_choice(const ilqr_ctx* c) { return c->xc_generic ? 1 : 2; }
 
 // The buffer table of one half of a split problem: every per-instance array is [..][Bp] with the instance innermost, so a half is the
 // same table with the base pointers moved by its first instance (gain records: by whole records) and its own descriptor (B = its size).
@@ -578,7 +585,7 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
     // number of step sizes the do/while of ILQRRecursive.cpp:101-155 can reach: 1, 1/2, ... until alpha <= alpha_floor
     int n_alpha = 1;
     if (line_search) { double al_ = 1.0; while (al_ > p->desc.alpha_floor && n_alpha < 64) { al_ *= 0.5; n_alpha++; } }
-    const int path = p->desc.limits2_set ? 1 : path_choice();  // a second limit set exists in the generic kernels only
+    const int path = p->desc.limits2_set ? 1 : path_choice(c);  // a second limit set exists in the generic kernels only
     const bool coop = (path != 1) && n_alpha <= 16;            // all step sizes at once (16 lanes / rows per instance)
     const bool fwd_wave = coop && forward_wave_supported(kind, nd, n_alpha);  // PosOrn-1 / JointSpace-1: linear line search, 32 lanes per instance
     const bool fwd_lin = coop && !fwd_wave && forward_lin_supported(kind, nd, n_alpha);  // PosOrn-2: linear line search, 8 lanes per instance
@@ -622,6 +629,17 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
         hv[0].bufs = p->bufs; hv[0].B = p->B; hv[0].st = c->stream;
     }
 
+    // Join on EVERY exit path: an early return between here and the end of the solve (a failed launch or event call on one half) must not
+    // leave work queued on a half stream that the context's stream never waits for -- the caller's next call would race with it.
+    struct SplitJoin {
+        ilqr_ctx* c; bool on;
+        ~SplitJoin() {
+            if (!on) return;
+            for (int i = 0; i < 2; i++)
+                if (hipEventRecord(c->ev_half_done[i], c->half_stream[i]) != hipSuccess || hipStreamWaitEvent(c->stream, c->ev_half_done[i], 0) != hipSuccess)
+                    (void)hipStreamSynchronize(c->half_stream[i]);  // last resort: drain it here
+        }
+    } split_join{c, split};
     FwdArgs f;
     std::memset(&f, 0, sizeof(f));
     f.line_search = line_search; f.early_stop = early_stop; f.nb_iter = nb_iter; f.penalty_roll = penalty0; f.n_alpha = n_alpha; f.al = al ? 1 : 0; f.n_kp = p->desc.n_kp;
@@ -703,12 +721,7 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
         sw.pen_in = fi.penalty_roll; sw.pen_update_prev = fi.penalty_update; sw.do_update_prev = fi.do_update;  // for the next sweep
         HIPCHK(c, hipGetLastError());
     }
-    if (split) {  // the caller's stream continues when both halves are done
-        for (int i = 0; i < 2; i++) {
-            HIPCHK(c, hipEventRecord(c->ev_half_done[i], c->half_stream[i]));
-            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_half_done[i], 0));
-        }
-    }
+    // (the caller's stream continues when both halves are done: SplitJoin below, on every exit path)
     prof_mark(c, -1);
     return 0;
 }
@@ -734,6 +747,7 @@ extern "C" int ilqr_solve_batch_cp(ilqr_problem* p, const double* psi, int Kw, i
         prof_mark(c, -1);
         return 0;
     }
+    p->cp.xc_lane_solve = c->xc_cp_lane; p->cp.xc_general = c->xc_cp_general;
     if (batchcp_solve(p->cp, p->hdesc, p->bufs, p->dims.n_x, p->dims.n_u, p->dims.n_f, p->dims.n_Q, psi, Kw, nb_iter, early_stop, c->stream, err, prof_hook(c)))
         return fail(c, err);
     prof_mark(c, -1);

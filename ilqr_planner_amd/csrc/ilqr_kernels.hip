@@ -72,7 +72,8 @@ __global__ __launch_bounds__(64) void k_kp_derivs(Bufs a, int fused) {
     constexpr int NX = S::NX;
     // origins and axes of the joints and the joint angles (7 x DOF per lane) for the rolled FK loop: a short launch between the streaming kernels is bound by
     // fetching its code, and the unrolled joints were most of it (ilqr_device.hpp: fk)
-    __shared__ double sj[7 * DOF][64];
+    constexpr int ROLLN = (!S::JOINT && S::ND == 1) ? 64 : 0;  // (2nd order: the rolled form spills more)
+    __shared__ double sj[ROLLN ? 7 * DOF : 1][64];  // (nothing reserved where the loop is not rolled)
     const DevDesc& d = *a.desc;
     const int b = blockIdx.x * 64 + threadIdx.x;
     const int kpi = blockIdx.y;
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(64) void k_kp_derivs(Bufs a, int fused) {
     const int k = d.kp_t[kpi];
     const int cur = a.cur[b];
     const double* X = a.X[cur];
-    double x[NX], lxx[NX][NX], lx[NX];
+    double x[NX];
     UNR for (int i = 0; i < NX; i++) x[i] = AT(X, k * NX + i, b);
     const int w = fused ? a.pend[b] - 1 : -1;
     if (w >= 0) {  // fused acceptance (FwdArgs::fused): the accepted state is still spread over the two buffers -- k_apply's expression
@@ -93,12 +94,12 @@ __global__ __launch_bounds__(64) void k_kp_derivs(Bufs a, int fused) {
             x[i] = (w == 0) ? x1 : fma(aa, x1 - x[i], x[i]);
         }
     }
-    stage_derivs<S, true, EXT, (!S::JOINT && S::ND == 1) ? 64 : 0>(d, a, b, x, kpi, lxx, lx, &sj[0][threadIdx.x]);  // (2nd order: the rolled form spills more)
+    // row by row straight to memory: the lane never holds the n_x x n_x matrix (it spilled for n_x = 14, 15)
     double* out = a.kpd + (size_t)kpi * (NX + NX * NX) * Bp;
-    UNR for (int i = 0; i < NX; i++) {
-        AT(out, i, b) = lx[i];
-        UNR for (int j = 0; j < NX; j++) AT(out, NX + i * NX + j, b) = lxx[i][j];
-    }
+    stage_derivs_rows<S, EXT, ROLLN>(d, a, b, x, kpi, &sj[0][threadIdx.x], [&](int i, const double* row, double lxi) {
+        AT(out, i, b) = lxi;
+        UNR for (int j = 0; j < NX; j++) AT(out, NX + i * NX + j, b) = row[j];
+    });
 }
 
 // Backward Riccati sweep (ILQRRecursive.cpp:68-97): writes K_k, d_k for k = T-2..0.  Needs k_kp_derivs first.

@@ -128,6 +128,90 @@ ILQR_DEV void stage_derivs(const DevDesc& d, const Bufs& a, int b, const double*
     }
 }
 
+// The same derivatives of a KEYPOINT stage handed out row by row -- sink(i, row_i of l_xx, l_x[i]) -- for k_kp_derivs: a lane that holds the
+// whole n_x x n_x matrix (225 doubles for n_x = 15) spills; a row at a time does not.  Expression for expression stage_derivs (same bits).
+template <class S, bool EXT, int ROLL, class Sink>
+ILQR_DEV void stage_derivs_rows(const DevDesc& d, const Bufs& a, int b, const double* x, int kpi, double* lj, Sink&& sink) {
+    constexpr int NX = S::NX, NQ = S::NQ, NF = S::NF;
+    const int Bp = d.Bp;
+    auto finish = [&](int i, double* row, double lxi) {  // limit terms of coordinate i (System.cpp:121-142), then out
+        if (d.limits_set && d.lw[i] != 0) {
+            double qv = 0, L = 0;
+            if (x[i] > d.smax[i]) { qv = d.smax[i] - x[i]; L = d.penalty; }
+            else if (x[i] < d.smin[i]) { qv = d.smin[i] - x[i]; L = d.penalty; }
+            lxi += -L * qv;
+            row[i] += (L != 0.0) ? d.pen_xx : 0.0;
+        }
+        sink(i, row, lxi);
+    };
+    if (!S::JOINT && EXT && S::ND == 1 && d.kp_joint[kpi]) {  // joint-space keypoint of a hybrid sequence (J = I, n_x x n_x precision)
+        const double* Q = d.kp_Q[kpi];
+        UNR for (int i = 0; i < NX; i++) {
+            double s = 0, row[NX];
+            UNR for (int j = 0; j < NX; j++) s += Q[i * NX + j] * (AT(a.kp_tg, kpi * NF + j, b) - x[j]);
+            UNR for (int j = 0; j < NX; j++) row[j] = 0.0 + Q[i * NX + j];
+            finish(i, row, 0.0 + -1 * s);
+        }
+    } else if (S::JOINT) {  // J = I: l_x = -Q e, l_xx = Q
+        double e[NQ], tg[NF];
+        UNR for (int i = 0; i < NF; i++) tg[i] = AT(a.kp_tg, kpi * NF + i, b);
+        kp_diff<S>(tg, x, e);
+        const double* Q = d.kp_Q[kpi];
+        UNR for (int i = 0; i < NQ; i++) {
+            double s = 0, row[NX];
+            UNR for (int j = 0; j < NQ; j++) s += Q[i * NQ + j] * e[j];
+            UNR for (int j = 0; j < NX; j++) row[j] = (j < NQ) ? 0.0 + Q[i * NQ + j] : 0.0;
+            finish(i, row, 0.0 + -1 * s);
+        }
+    } else {
+        double fxv[NF], J[6][DOF], e[NQ], tg[NF], Qe[NQ];
+        fx_of<S, true, ROLL>(d, x, fxv, J, EXT ? kpi : -1, lj);
+        UNR for (int i = 0; i < NF; i++) tg[i] = AT(a.kp_tg, kpi * NF + i, b);
+        kp_diff<S>(tg, fxv, e);
+        if (EXT) kp_deadzone(d, kpi, e);
+        const double* Q = d.kp_Q[kpi];
+        UNR for (int i = 0; i < NQ; i++) {
+            double s = 0;
+            UNR for (int j = 0; j < NQ; j++) s += Q[i * NQ + j] * e[j];
+            Qe[i] = s;
+        }
+        // Jf (NQ x NX) = blkdiag(J, J) bordered by 1 for the time state; lx = -Jf^T Q e ; lxx = Jf^T Q Jf
+        UNR for (int blk = 0; blk < S::ND; blk++) {
+            UNR for (int c = 0; c < DOF; c++) {
+                double sl = 0;
+                UNR for (int r = 0; r < 6; r++) sl += J[r][c] * Qe[6 * blk + r];
+                double jq[NQ], row[NX];
+                UNR for (int rp = 0; rp < NQ; rp++) {
+                    double s = 0;
+                    UNR for (int r = 0; r < 6; r++) s += J[r][c] * Q[(6 * blk + r) * NQ + rp];
+                    jq[rp] = s;
+                }
+                UNR for (int blk2 = 0; blk2 < S::ND; blk2++) {
+                    UNR for (int c2 = 0; c2 < DOF; c2++) {
+                        double s = 0;
+                        UNR for (int r = 0; r < 6; r++) s += jq[6 * blk2 + r] * J[r][c2];
+                        row[DOF * blk2 + c2] = 0.0 + s;
+                    }
+                }
+                if (S::TM) row[NX - 1] = 0.0 + jq[NQ - 1];
+                finish(DOF * blk + c, row, 0.0 + -1 * sl);
+            }
+        }
+        if (S::TM) {
+            double row[NX];
+            UNR for (int blk2 = 0; blk2 < S::ND; blk2++) {
+                UNR for (int c2 = 0; c2 < DOF; c2++) {
+                    double s = 0;
+                    UNR for (int r = 0; r < 6; r++) s += Q[(NQ - 1) * NQ + 6 * blk2 + r] * J[r][c2];
+                    row[DOF * blk2 + c2] = 0.0 + s;
+                }
+            }
+            row[NX - 1] = 0.0 + Q[(NQ - 1) * NQ + NQ - 1];
+            finish(NX - 1, row, 0.0 + -1 * Qe[NQ - 1]);
+        }
+    }
+}
+
 // Eigen MatrixXd::inverse() (PartialPivLU + solve against identity), fully unrolled, no dynamic indexing.
 template <int N>
 ILQR_DEV void inverse_lu(double (*M)[N], double (*Inv)[N]) {

@@ -152,6 +152,11 @@ int ilqr_ctx_synchronize(ilqr_ctx* ctx);
  * context's stream by events (instances are independent: results do not depend on it).  on = 0 keeps every launch on the context's
  * stream, one kernel at a time -- what a profiler run wants.  Default: on.  (No reference counterpart: the reference has no batch.) */
 int ilqr_ctx_set_split(ilqr_ctx* ctx, int on);
+/* Cross-check kernel variants for parity tests (no reference counterpart; the library reads no environment variable -- these are context state,
+ * in force for every later solve on the context): generic_kernels = 1 runs ILQRRecursive / AL_ILQR on the generic one-lane-per-instance kernel
+ * set instead of the cooperative one; cp_lane_solve = 1 solves the Batch-CP normal equations with one lane per instance instead of one wave;
+ * cp_general = 1 sends Batch-CP on the constant-dt systems through the general path of the time systems.  All 0 = the product path. */
+int ilqr_ctx_set_crosscheck(ilqr_ctx* ctx, int generic_kernels, int cp_lane_solve, int cp_general);
 const char* ilqr_version(void);
 
 /* ---- a batch of B instances of one System ---------------------------------------------------------------- */
