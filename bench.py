@@ -79,11 +79,11 @@ def gather_step(local_cost, total, local_X=None, local_U=None):
 # ----------------------------------------------------------------------------- roofline bookkeeping
 
 def pmc_traffic(config, category):
-    """HBM bytes per launch of a kernel category from the committed rocprofv3 --pmc summary of this round (profiles/r02_<config>_kernels.txt;
+    """HBM bytes per launch of a kernel category from the committed rocprofv3 --pmc summary of this round (profiles/r03_<config>_kernels.txt;
     two separate passes FETCH_SIZE / WRITE_SIZE; on gfx950 FETCH_SIZE counts half of a coalesced stream and is doubled --
     MI355X_MICROARCH.md).  bench.py cannot run the profiler around itself: the summary is produced by scripts/collect_profiles.sh with
     this same command.  Returns (bytes or None, source)."""
-    f = os.path.join(ROOT, "profiles", f"r02_{config.lower()}_kernels.txt")
+    f = os.path.join(ROOT, "profiles", f"r03_{config.lower()}_kernels.txt")
     if not os.path.exists(f):
         return None, None
     fetch = write = None
@@ -297,7 +297,7 @@ def parity_report(ctx, cfg, desc, inp, B, nb_iter, oracle_res):
                    "one oracle iteration from the GPU's own state: the GPU's trajectory handed over, the GPU's accept / reject decisions following "
                    "from the ORACLE's cost of every step size, the cost at the GPU's step size equal to 1e-9 (stepwise), up to comparisons decided "
                    "inside 1e-9 of the oracle's own cost0 (tie; n_tie_decisions) and steps whose deviation the oracle's own neutral variants "
-                   "reproduce or exceed (n_steps_ill_conditioned, worst_ill_ratio = deviation / largest variant sensitivity, gate <= 4).  "
+                   "reproduce or exceed (n_steps_ill_conditioned, worst_ill_ratio = deviation / largest sensitivity over the oracle's neutral variants and one-ulp input perturbations, gate <= 10).  "
                    "oracle_self_consistency = the oracle against its own neutral variants end to end: the share within 1e-4 there is what the "
                    "reference's expanding, discontinuous map allows ANY second implementation on this non-converged workload; "
                    "converged = the same instances run to the reference's own stopping test")
@@ -441,6 +441,17 @@ def main():
                         timing="HIP events on the library's stream, separate pass after the timed region")
             if trials is not None:
                 roof["mean_line_search_trials"] = round(trials, 3)
+            # what share of the solve the rated kernels are: a roofline fraction speaks for its own kernel only
+            tot_ms = sum(v["total_ms"] for v in kern.values())
+            roof["rated_share_of_solve"] = round(sum(v["total_ms"] for v in rated.values()) / tot_ms, 4) if tot_ms else None
+            roof["dominant_share_of_solve"] = round(k["total_ms"] / tot_ms, 4) if tot_ms else None
+            if not riccati:  # Batch-CP: the horizon is walked twice per solve (rated); the iterations work on keypoint-sized data
+                unr = {n_: round(v["total_ms"] / tot_ms, 4) for n_, v in kern.items() if n_ not in rated}
+                roof["unrated"] = {"share_of_solve": unr, "bound": "latency",
+                                   "note": "backward = linearize + solve of the 14 x 14 normal equations, forward = the two line-search passes: per-iteration launches on "
+                                           "keypoint-sized data (7 x 14 W, 14 x 14 H), each the chain of ONE FK / cost evaluation or ONE solve at one to two waves per SIMD; "
+                                           "SQ_WAIT_ANY / SQ_WAVE_CYCLES = 52-77 % (profiles/r02_sq_counters.txt): no memory or matrix-core roofline applies, "
+                                           "the figure of the rated kernel is NOT the configuration's"}
         kinds = ("PosOrn", "PosOrnTime", "JointSpace", "JointSpaceTime")
         out = {
             "metric": METRIC,

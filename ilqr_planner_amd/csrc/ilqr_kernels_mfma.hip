@@ -61,6 +61,43 @@ __device__ __forceinline__ double cross_rows_sum(double v) {  // sum over lanes 
 }
 __device__ __forceinline__ double wave_sum_m(double v) { return cross_rows_sum(row16_sum(v)); }
 
+
+// ---- Quu + reg I inverted in REGISTERS (round 3).  The 8 x 8 matrix was swept in LDS, one entry per lane: per pivot three dependent LDS
+// reads, the reciprocal, one FMA and an LDS write -- ~280 clocks of a lone wave's chain, eight times per step, more than half of the
+// step.  Now every lane reads ROW (c16 & 7) of the matrix once (the four DPP rows of the wave hold four copies) and the pivots run as in
+// ilqr_kernels_dpp.hip: the pivot row is the DPP operand of the FMA (v_fmac_f64_dpp ... row_newbcast:c), deferred row scaling, no LDS.
+// NP pivots (= n_u: 7 or 8) over NP columns; hazards as explained there (two wait states before a DPP read of a freshly written register).
+#define MPV_ALL_ " row_mask:0xf bank_mask:0xf"
+#define MPV_HEAD_(C) "v_mov_b64_dpp %[acc], %[s" #C "] row_newbcast:" #C MPV_ALL_ "\n\t"
+#define MPV_RCP_(C)                                                                        \
+    "v_rcp_f64 %[rc], %[acc]\n\t"                                                          \
+    "v_fma_f64 %[t], %[s" #C "], %[n" #C "], %[s" #C "]\n\t"                               \
+    "v_fma_f64 %[e], -%[acc], %[rc], 1.0\n\t"                                              \
+    "v_fma_f64 %[e], %[e], %[e], %[e]\n\t"                                                 \
+    "v_fma_f64 %[rc], %[e], %[rc], %[rc]\n\t"                                              \
+    "v_mul_f64 %[t], %[t], %[rc]\n\t"
+#define MPV_F_(J, C) "v_fmac_f64_dpp %[s" #J "], %[s" #J "], -%[t] row_newbcast:" #C MPV_ALL_ "\n\t"
+#define MPV_TAIL_(C) "v_add_f64 %[s" #C "], %[t], %[n" #C "]\n\tv_fma_f64 %[myrc], -%[rc], %[n" #C "], %[myrc]\n\t"
+#define MPV7_(C, A, B, D, E, F, G) MPV_HEAD_(C) MPV_RCP_(C) MPV_F_(A, C) MPV_F_(B, C) MPV_F_(D, C) MPV_F_(E, C) MPV_F_(F, C) MPV_F_(G, C) MPV_TAIL_(C)
+#define MPV8_(C, A, B, D, E, F, G, H) MPV_HEAD_(C) MPV_RCP_(C) MPV_F_(A, C) MPV_F_(B, C) MPV_F_(D, C) MPV_F_(E, C) MPV_F_(F, C) MPV_F_(G, C) MPV_F_(H, C) MPV_TAIL_(C)
+template <int NP>
+__device__ __forceinline__ void quu_pivots(double (&s)[8], const double (&nm1)[8], double& myrc) {
+    double acc, rc, e, t;
+    if (NP == 8) {
+        asm volatile("s_nop 1\n\t" MPV8_(0, 1, 2, 3, 4, 5, 6, 7) MPV8_(1, 0, 2, 3, 4, 5, 6, 7) MPV8_(2, 0, 1, 3, 4, 5, 6, 7) MPV8_(3, 0, 1, 2, 4, 5, 6, 7)
+                         MPV8_(4, 0, 1, 2, 3, 5, 6, 7) MPV8_(5, 0, 1, 2, 3, 4, 6, 7) MPV8_(6, 0, 1, 2, 3, 4, 5, 7) MPV8_(7, 0, 1, 2, 3, 4, 5, 6) "s_nop 0"
+                     : [acc] "=&v"(acc), [rc] "=&v"(rc), [e] "=&v"(e), [t] "=&v"(t), [s0] "+v"(s[0]), [s1] "+v"(s[1]), [s2] "+v"(s[2]), [s3] "+v"(s[3]),
+                       [s4] "+v"(s[4]), [s5] "+v"(s[5]), [s6] "+v"(s[6]), [s7] "+v"(s[7]), [myrc] "+v"(myrc)
+                     : [n0] "v"(nm1[0]), [n1] "v"(nm1[1]), [n2] "v"(nm1[2]), [n3] "v"(nm1[3]), [n4] "v"(nm1[4]), [n5] "v"(nm1[5]), [n6] "v"(nm1[6]), [n7] "v"(nm1[7]));
+    } else {
+        asm volatile("s_nop 1\n\t" MPV7_(0, 1, 2, 3, 4, 5, 6) MPV7_(1, 0, 2, 3, 4, 5, 6) MPV7_(2, 0, 1, 3, 4, 5, 6) MPV7_(3, 0, 1, 2, 4, 5, 6) MPV7_(4, 0, 1, 2, 3, 5, 6)
+                         MPV7_(5, 0, 1, 2, 3, 4, 6) MPV7_(6, 0, 1, 2, 3, 4, 5) "s_nop 0"
+                     : [acc] "=&v"(acc), [rc] "=&v"(rc), [e] "=&v"(e), [t] "=&v"(t), [s0] "+v"(s[0]), [s1] "+v"(s[1]), [s2] "+v"(s[2]), [s3] "+v"(s[3]),
+                       [s4] "+v"(s[4]), [s5] "+v"(s[5]), [s6] "+v"(s[6]), [myrc] "+v"(myrc)
+                     : [n0] "v"(nm1[0]), [n1] "v"(nm1[1]), [n2] "v"(nm1[2]), [n3] "v"(nm1[3]), [n4] "v"(nm1[4]), [n5] "v"(nm1[5]), [n6] "v"(nm1[6]));
+    }
+}
+
 template <class S, bool AL>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_backward_mfma(Bufs a) {
     constexpr int NX = S::NX, NU = S::NU, ND = S::ND, TM = S::TM;
@@ -71,7 +108,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     static_assert(NX <= 15 && NU <= 8, "one affine column next to the state, two k-steps of 4");
     __shared__ __attribute__((aligned(16))) double sP[16][PS], sBtP[8][PS], sS[8][TS], sQuu[8][TS];
     __shared__ double sLx[16], sLxx[16];  // limit terms of the step (entry 15: constant 0)
-    __shared__ double sD[8];  // the diagonal of the matrix under the sweeps (its places in sS hold the constant -1, see there)
     __shared__ __attribute__((aligned(16))) double sx[16], su[8], sbc[16], sp[16], slam[MMAX], sIs[MMAX];
     __shared__ double sDump[64];  // target of the stores of lanes that own nothing: an unconditional ds_write is cheaper than an exec-mask branch
 
@@ -95,8 +131,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (l < 16) { sx[l] = 0; sbc[l] = 0; sp[l] = 0; slam[l] = 0; sIs[l] = 0; sLx[l] = 0; sLxx[l] = 0; }
     if (l < 8) su[l] = 0;
     LDS_ORDER();
-    if (l < 8) { sS[l][l] = -1.0; sD[l] = 0; }
-    LDS_ORDER();
 
     // ---- lane maps
     const bool colS = c16 < NX;      // this lane's column is a state column
@@ -116,7 +150,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     double* const dump = &sDump[l];
     double* wBtP[2];
     UNR for (int r = 0; r < 2; r++) wBtP[r] = (uv[r] && colS) ? &sBtP[ui[r]][c16] : dump;
-    double* const wS = qv ? ((qi == qj) ? &sD[qi] : &sS[qi][qj]) : dump;
+    double* const wS = qv ? &sS[qi][qj] : dump;
     double* const wQuu = qv ? &sQuu[qi][qj] : dump;
     double* wP[4];
     UNR for (int r = 0; r < 4; r++) wP[r] = (pv[r] && colS) ? &sP[pi[r]][c16] : ((pv[r] && colA) ? &sp[pi[r]] : dump);
@@ -136,11 +170,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     UNR for (int r = 0; r < 4; r++)
         rdL[r] = (pv[r] && colA) ? &sLx[pi[r]] : ((pv[r] && colS && pi[r] == c16) ? &sLxx[pi[r]] : &sLxx[15]);
 
-    double pvm[NU];  // sweep of pivot c: 0 for the entries of row / column c, 1 elsewhere (below)
-    UNR for (int c = 0; c < NU; c++) pvm[c] = (qi == c || qj == c) ? 0.0 : 1.0;
-    const int cu_ = (c16 < NU) ? c16 : 0;
-    const double* const rdS0 = (cu_ == h) ? &sD[cu_] : &sS[cu_][h];
-    const double* const rdS1 = (cu_ == 4 + h) ? &sD[cu_] : &sS[cu_][4 + h];
+    double nm1q[8];  // quu_pivots: -1 in the lane whose row is the pivot row of pivot c, 0 elsewhere
+    UNR for (int c = 0; c < 8; c++) nm1q[c] = ((c16 & 7) == c) ? -1.0 : 0.0;
     // control weights of the rows this lane works on: out of the descriptor once (read inside the loop they are a global load and an
     // s_waitcnt vmcnt(0) per step -- which also waits for the whole prefetch ring)
     const double Ru[2] = {d.R_diag[ui[0]], d.R_diag[ui[1]]};
@@ -341,33 +372,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         const double s0 = quu + ((qi == qj) ? reg : 0.0);
         *wS = s0;
         LDS_ORDER();
-        // ---- 5. symmetric sweeps on Quu + reg I: afterwards sS = -(Quu + reg I)^-1 = Quu_inv of the reference
+        // ---- 5. Quu_inv = -(Quu + reg I)^-1: row (c16 & 7) of Quu + reg I out of LDS once, the pivots in registers (quu_pivots above);
+        //         afterwards myrc * srow = this lane's row of Quu_inv
+        double srow[8], myrc = 0.0;
         {
-            double sv = s0;
-            UNR for (int c = 0; c < NU; c++) {
-                // ONE expression for all entries (as the single-integrator sweep did while it kept its matrices in LDS): the entries of the pivot row / column read the constant -1 for "their"
-                // a_ic / a_cj and take 0 for their own value, which turns  s - (a_ic r) a_cj  into  a_ic r  (column c),  a_cj r  (row c) and
-                // -r  (the pivot) with the bits of the direct expressions -- instead of three selects per pivot.  The -1 sits on the diagonal
-                // of sS for good: the diagonal entries live in sD (written there by their lanes, read from there as the pivot and, below, as
-                // operand of the products), so a_ic = sS[i][c] IS -1 for i = c without any choice of address.
-                const double aic = sS[qi][c];
-                const double acj = sS[c][qj];
-                const double acc = sD[c];
-                LDS_ORDER();
-                const double r = rcp_nr_m(acc);  // (forming the next pivot's reciprocal early, as the LDS-resident single-integrator sweep does, costs three more broadcast reads
-                                                 // per pivot here and measured 3 % slower)
-                const double tt = aic * r;
-                const double val = fma(-tt, acj, sv * pvm[c]);
-                sv = val;
-                *wS = val;
-                LDS_ORDER();
-            }
+            const d4_t* rp = reinterpret_cast<const d4_t*>(&sS[c16 & 7][0]);  // rows are 80 bytes apart: 16-byte aligned
+            const double2 r0 = reinterpret_cast<const double2*>(rp)[0], r1 = reinterpret_cast<const double2*>(rp)[1], r2 = reinterpret_cast<const double2*>(rp)[2],
+                          r3 = reinterpret_cast<const double2*>(rp)[3];
+            srow[0] = r0.x; srow[1] = r0.y; srow[2] = r1.x; srow[3] = r1.y; srow[4] = r2.x; srow[5] = r2.y; srow[6] = r3.x; srow[7] = r3.y;
         }
+        quu_pivots<NU>(srow, nm1q, myrc);
         // ---- 6. K~ = Quu_inv Qux~ ; T1~ = Quu K~ + Qux~ ; P~' = [Qxx | Qx] + K~^T T1~ + Qxu K~   (f64 matrix cores)
         const bool rowU = c16 < NU;
         const int cu = rowU ? c16 : 0;
         const double mU = rowU ? 1.0 : 0.0;  // (a factor, not a select: a select of a load is compiled as an exec-mask region around the load)
-        const double sa0 = *rdS0 * mU, sa1 = *rdS1 * mU;                   // A operand: Quu_inv[c16][4c + h] (diagonal entries from sD)
+        // A operand: Quu_inv[c16][h], Quu_inv[c16][4 + h] -- entries h, 4 + h of this lane's row (h is the lane's DPP row: a select among four)
+        const double lo01 = (h & 1) ? srow[1] : srow[0], lo23 = (h & 1) ? srow[3] : srow[2], hi01 = (h & 1) ? srow[5] : srow[4], hi23 = (h & 1) ? srow[7] : srow[6];
+        const double msc = (c16 < 8 ? myrc : 0.0) * mU;                       // (rows live in lanes c16 < 8; the copies in 8..15 feed zeros)
+        const double sa0 = ((h & 2) ? lo23 : lo01) * msc, sa1 = ((h & 2) ? hi23 : hi01) * msc;
         const double qa0 = sQuu[cu][h] * mU, qa1 = sQuu[cu][4 + h] * mU;   // A operand: Quu[c16][4c + h]
         d4_t Kt = {0, 0, 0, 0};
         Kt = __builtin_amdgcn_mfma_f64_16x16x4f64(sa0, qux[0], Kt, 0, 0, 0);

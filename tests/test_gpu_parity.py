@@ -386,3 +386,40 @@ def test_tracking_and_warm_start_vs_oracle(ctx):
         r2 = orc.solve_recursive(s, U0.reshape(-1), n2, True, False)
         assert abs(cost2[i] - r2["cost"]) <= 1e-4 * max(abs(r2["cost"]), 1e-9), (i, cost2[i], r2["cost"])  # two chained solves: the north star's tolerance
     p.close()
+
+
+def test_al_batch_then_new_context_then_generic_al_tutorial(monkeypatch):
+    """The launch sequence of round 1's memory fault, kept as an ordinary test (run once with the suite, never looped): a large AL batch on
+    one context, the context closed, a NEW context, then the 62-iteration AL tutorial solve on the generic lane-per-instance kernels.
+    The kernel class that faulted is gone (the generic sweep holds its matrices in an explicit workspace: no scratch, no hidden LDS --
+    DESIGN.md 5.5); the test pins that the sequence runs and still reproduces the notebook's trace."""
+    from ilqr_planner_amd import capi, workloads
+
+    c1 = capi.Context(0)
+    cfg = workloads.config("C3")
+    desc, inp = workloads.make_batch(c1, cfg, B=1024)
+    p = workloads.load_batch(c1, desc, inp, 1024)
+    workloads.run_solver(p, cfg, nb_iter=6, early_stop=False)
+    assert np.isfinite(p.cost()).mean() > 0.99
+    p.close()
+    c1.close()
+    monkeypatch.setenv("ILQR_HIP_PATH", "v1")
+    c2 = capi.Context(0)
+    case = golden()["cases"]["POS_ORN_SYS_AL_ILQR"]
+    sv = [s for s in case["solves"] if s["solver"] == "AL_ILQR"][0]
+    q = _tutorial_problem(c2, case, 3)
+    nxu = q.dims.n_x + q.dims.n_u
+    A, b = np.zeros((sv["m"], nxu)), np.zeros(sv["m"])
+    for i, j, v in sv["A_nonzero"]:
+        A[i, j] = v
+    for i, v in sv["b_nonzero"]:
+        b[i] = v
+    q.set_constraints(A, b, np.tile(b, (3, q.T - 1, 1)))
+    q.solve_al(sv["nb_iter"], sv["lag_update_step"], sv["penalty"], sv["scaling_factor"], sv["line_search"], sv["early_stop"])
+    ct, at = q.trace(sv["nb_iter"])
+    nref = len(sv["trace"])
+    for b_ in range(3):
+        assert q.iters()[b_] == nref
+        assert_trace(ct[b_, :nref], at[b_, :nref], sv["trace"], 0.51)
+    q.close()
+    c2.close()
