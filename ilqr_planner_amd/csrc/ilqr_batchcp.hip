@@ -429,7 +429,7 @@ template <class S, int KWP>
 __global__ __launch_bounds__(LPB) void k_cpl_linearize(Bufs a, CPArgs c) {
     constexpr int NX = S::NX;
     constexpr int ROLL = (!S::JOINT && S::ND == 1) ? LPB : 0;  // rolled FK joint loop, its per-joint values in LDS (ilqr_device.hpp: fk)
-    __shared__ double sj[7 * DOF][LPB];
+    __shared__ double sj[ROLL ? 7 * DOF : 1][LPB];  // (nothing reserved where the loop is not rolled)
     const DevDesc& d = *a.desc;
     const int b = blockIdx.x * LPB + threadIdx.x, kpi = blockIdx.y;
     if (b >= d.B || !a.active[b]) return;

@@ -130,3 +130,33 @@ def test_full_size_properties(ctx, cfg_name, B, nb_iter, solver):
         small["p"].close()
         print(f"parity {cfg_name} full size: {summ}")
         assert not failures, f"{len(failures)} instance(s) neither within 1e-4 nor proven: {failures[:3]}"
+
+
+@pytest.mark.parametrize("cfg_name,solver", [("C3", "al"), ("C2", "recursive")])
+def test_sweep_lane_groupings_agree(ctx, cfg_name, solver):
+    """The register-resident sweep of the single-integrator systems runs with 16 lanes per instance while that gives every SIMD at most one
+    wave and with 8 lanes per instance (two instances per DPP row, every broadcast issued once per half with a bank mask) beyond: a batch
+    just over 4 x 1024 instances takes the second form, a 61-instance cut-out of it the first.  Same operations on the same operands in the
+    same order in both: bit-identical results, whichever half of a DPP row an instance sits in; the cut-out then goes through the
+    per-instance proof."""
+    from ilqr_planner_amd import workloads
+    from tests import parity_proof as pp
+
+    cfg = dict(workloads.config(cfg_name), T=40)
+    B, nb_iter = 4200, 6
+    desc, inp = workloads.make_batch(ctx, cfg, B=B)
+    big = _solve(ctx, cfg, desc, inp, B, nb_iter, solver)
+    rng = np.random.default_rng(11)
+    idx = np.sort(rng.choice(B, 61, replace=False))
+    desc_s, _ = workloads.make_batch(ctx, cfg, B=len(idx))
+    inp_s = _take(inp, idx)
+    small = _solve(ctx, cfg, desc_s, inp_s, len(idx), nb_iter, solver, keep=True)
+    np.testing.assert_array_equal(small["cost"], big["cost"][idx])
+    np.testing.assert_array_equal(small["U"], big["U"][idx])
+    np.testing.assert_array_equal(small["X"], big["X"][idx])
+    np.testing.assert_array_equal(small["trace"], big["trace"][idx])
+    segs = panda_segs()
+    summ, _, failures = pp.check_batch(small["p"], cfg, inp_s, nb_iter, False, workloads.run_solver,
+                                       lambda i: oracle_solve_instance(cfg, inp_s, i, nb_iter, False, segs), always=(0, 1, 2, 3))
+    small["p"].close()
+    assert not failures, f"{len(failures)} instance(s) neither within 1e-4 nor proven: {failures[:3]}"
