@@ -108,7 +108,7 @@ def load():
     L.ilqr_ctx_set_stream.argtypes = [vp, vp]
     L.ilqr_ctx_synchronize.argtypes = [vp]
     L.ilqr_ctx_set_split.argtypes = [vp, C.c_int]
-    L.ilqr_ctx_set_crosscheck.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.ilqr_ctx_set_crosscheck.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
     L.ilqr_problem_create.argtypes = [vp, C.POINTER(ProblemDesc), C.c_int, C.POINTER(vp)]
     L.ilqr_problem_destroy.argtypes = [vp]
     L.ilqr_problem_destroy.restype = None
@@ -260,14 +260,15 @@ class Context:
     def synchronize(self):
         self.check(self.L.ilqr_ctx_synchronize(self.h))
 
-    def set_crosscheck(self, generic_kernels=False, cp_lane_solve=False, cp_general=False):
+    def set_crosscheck(self, generic_kernels=False, cp_lane_solve=False, cp_general=False, mfma_sweep=0):
         """Cross-check kernel variants (ilqr_ctx_set_crosscheck); context state, in force until changed."""
-        self.check(self.L.ilqr_ctx_set_crosscheck(self.h, int(bool(generic_kernels)), int(bool(cp_lane_solve)), int(bool(cp_general))))
+        self.check(self.L.ilqr_ctx_set_crosscheck(self.h, int(bool(generic_kernels)), int(bool(cp_lane_solve)), int(bool(cp_general)), int(mfma_sweep)))
 
     def crosscheck_from_env(self):
         """TEST PLUMBING of this Python wrapper (the library itself reads no environment variable): the parity tests select the cross-check
-        variants per test case through ILQR_HIP_PATH=v1, ILQR_CP_SOLVE=lane, ILQR_CP=general; every solve of BatchProblem passes them on."""
-        self.set_crosscheck(os.environ.get("ILQR_HIP_PATH") == "v1", os.environ.get("ILQR_CP_SOLVE") == "lane", os.environ.get("ILQR_CP") == "general")
+        variants per test case through ILQR_HIP_PATH=v1, ILQR_CP_SOLVE=lane, ILQR_CP=general, ILQR_SWEEP=mfma|rows; every solve of BatchProblem passes them on."""
+        self.set_crosscheck(os.environ.get("ILQR_HIP_PATH") == "v1", os.environ.get("ILQR_CP_SOLVE") == "lane", os.environ.get("ILQR_CP") == "general",
+                            {"mfma": 1, "rows": 2}.get(os.environ.get("ILQR_SWEEP"), 0))
 
     def set_split(self, on: bool):
         """Two-stream solve of large batches on / off (ilqr_ctx_set_split); off = one kernel at a time, for profiler runs."""

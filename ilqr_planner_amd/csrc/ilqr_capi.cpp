@@ -37,6 +37,7 @@ struct ilqr_ctx {
     // split solves (solve_riccati): the two halves of a batch run on their own streams, joined to `stream` by events
     int n_simd = 1024;  // SIMDs of the device (4 per CU)
     bool xc_generic = false, xc_cp_lane = false, xc_cp_general = false;  // cross-check kernel variants (ilqr_ctx_set_crosscheck)
+    int xc_sweep = 0;  // sweep of the 2nd-order / time systems: 0 = by batch size, 1 = matrix-core sweep, 2 = row sweep
     hipStream_t half_stream[2] = {nullptr, nullptr};
     hipEvent_t ev_begin = nullptr, ev_half_done[2] = {nullptr, nullptr}, ev_stagger = nullptr;
 };
@@ -161,8 +162,9 @@ extern "C" int ilqr_ctx_set_split(ilqr_ctx* c, int on) {
     return 0;
 }
 
-extern "C" int ilqr_ctx_set_crosscheck(ilqr_ctx* c, int generic_kernels, int cp_lane_solve, int cp_general) {
+extern "C" int ilqr_ctx_set_crosscheck(ilqr_ctx* c, int generic_kernels, int cp_lane_solve, int cp_general, int mfma_sweep) {
     if (!c) return 1;
+    c->xc_sweep = (mfma_sweep == 1 || mfma_sweep == 2) ? mfma_sweep : 0;
     c->xc_generic = generic_kernels != 0;
     c->xc_cp_lane = cp_lane_solve != 0;
     c->xc_cp_general = cp_general != 0;
@@ -594,6 +596,9 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
     const bool off32 = (size_t)2 * p->T * p->dims.n_x * p->Bp * 8 < ((size_t)1 << 32) && (size_t)p->T * (p->bufs.m > 0 ? p->bufs.m : 1) * p->Bp * 8 < ((size_t)1 << 32);
     const bool bwd_si = (path != 1) && off32 && backward_si_supported(kind, nd, al, p->bufs.m, p->bufs.per_step, p->con_state_only);
     const bool bwd_mfma = (path != 1) && !bwd_si && backward_mfma_supported(kind, nd, al, p->bufs.m);  // wave per instance, f64 matrix cores
+    // 16 lanes per instance, rows in registers (round 3): a lone wave's chain is longer than the matrix-core sweep's (553 against 316 us at the C4 shape), but four
+    // instances share a wave: it wins as soon as the wave-per-instance sweep needs a second round of waves (measured: B = 2048 600 against 548 us, B = 4096 597 against 1040)
+    const bool bwd_rows = bwd_mfma && c->xc_sweep != 1 && (c->xc_sweep == 2 || p->B > 2 * c->n_simd) && backward_rows_supported(kind, nd, al, p->bufs.m);
     bool uniform_R = true;
     for (int i = 1; i < p->dims.n_u; i++) uniform_R = uniform_R && (p->desc.R_diag[i] == p->desc.R_diag[0]);
     const bool fused = bwd_si && fwd_wave;  // the sweep applies the previous line search's winner itself (ilqr_kernels_dpp.hip)
@@ -609,7 +614,7 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
     // workgroups on 3072 wave slots otherwise leave a one-third-full second round), not for the single-integrator pipeline (C3: the forward
     // pass slows from 0.125 to 0.24 ms and k_kp_derivs from 0.017 to 0.08-0.14 ms when they share the SIMDs with the other half's sweep:
     // 0.53 ms per iteration against 0.49 unsplit).
-    const bool split = coop && bwd_mfma && c->split && !c->profile && p->ddesc_half[0] && nb_iter > 0;
+    const bool split = coop && bwd_mfma && !bwd_rows && c->split && !c->profile && p->ddesc_half[0] && nb_iter > 0;
     if (!bwd_si && !bwd_mfma && nb_iter > 0 && !p->bufs.ws)  // the generic sweep keeps the matrices of a step in an explicit workspace
         if (dalloc(p, &p->bufs.ws, (size_t)backward_ws_entries(kind, nd) * p->Bp, false)) return 1;
     if (split) {
@@ -686,6 +691,7 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
                 // (the launch is then bound by one wave's instruction stream, which is shorter with 4 instances per wave), 8 lanes per
                 // instance beyond (half the instructions per instance).  Measured crossover between 4096 and 8192 instances on 1024 SIMDs.
                 if (bwd_si) launch_backward_si_dpp(al, fused, uniform_R, (B + 3) / 4 <= c->n_simd ? 16 : 8, bf, B, st, sw);
+                else if (bwd_rows) launch_backward_rows(kind, nd, al, bf, B, st);
                 else if (bwd_mfma) launch_backward_mfma(kind, nd, al, bf, B, st);
                 else launch_solver(kind, nd, KER_BACKWARD, al, bf, B, st, fi);
             }

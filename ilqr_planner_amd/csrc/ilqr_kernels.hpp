@@ -76,6 +76,8 @@ bool backward_si_supported(int kind, int nd, bool al, int m, int per_step, bool 
 void launch_solver_v2(int kind, int nd, int which, bool al, const Bufs& a, int B, int T, hipStream_t st, const FwdArgs& f);
 void launch_backward_si_dpp(bool al, bool fused, bool uniform_R, int lpi, const Bufs& a, int B, hipStream_t st, const SweepArgs& sw);  // rows in registers, DPP broadcasts (ilqr_kernels_dpp.hip)
 bool backward_mfma_supported(int kind, int nd, bool al, int m);
+bool backward_rows_supported(int kind, int nd, bool al, int m);  // row-per-lane register sweep of the general systems (ilqr_kernels_rowsweep.hip)
+void launch_backward_rows(int kind, int nd, bool al, const Bufs& a, int B, hipStream_t st);  // needs KER_KP_DERIVS first
 int backward_ws_entries(int kind, int nd);  // doubles per instance of k_backward's workspace
 void launch_backward_mfma(int kind, int nd, bool al, const Bufs& a, int B, hipStream_t st);  // needs KER_KP_DERIVS first
 bool forward_lin_supported(int kind, int nd, int n_alpha);

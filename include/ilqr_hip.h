@@ -155,8 +155,11 @@ int ilqr_ctx_set_split(ilqr_ctx* ctx, int on);
 /* Cross-check kernel variants for parity tests (no reference counterpart; the library reads no environment variable -- these are context state,
  * in force for every later solve on the context): generic_kernels = 1 runs ILQRRecursive / AL_ILQR on the generic one-lane-per-instance kernel
  * set instead of the cooperative one; cp_lane_solve = 1 solves the Batch-CP normal equations with one lane per instance instead of one wave;
- * cp_general = 1 sends Batch-CP on the constant-dt systems through the general path of the time systems.  All 0 = the product path. */
-int ilqr_ctx_set_crosscheck(ilqr_ctx* ctx, int generic_kernels, int cp_lane_solve, int cp_general);
+ * cp_general = 1 sends Batch-CP on the constant-dt systems through the general path of the time systems; mfma_sweep selects the backward sweep of
+ * the 2nd-order / time systems: 0 = by batch size (one instance per wave on the f64 matrix cores up to two waves per SIMD, 16 lanes per instance
+ * with rows in registers beyond), 1 = always the former, 2 = always the latter (the two agree to rounding, not bit for bit).
+ * All 0 = the product path. */
+int ilqr_ctx_set_crosscheck(ilqr_ctx* ctx, int generic_kernels, int cp_lane_solve, int cp_general, int mfma_sweep);
 const char* ilqr_version(void);
 
 /* ---- a batch of B instances of one System ---------------------------------------------------------------- */

@@ -55,8 +55,11 @@ def _solve(ctx, cfg, desc, inp, B, nb_iter, solver, keep=False):
 
 @pytest.mark.parametrize("cfg_name,B,nb_iter,solver", [("C3", 4096, 20, "al"), ("C4", 32768, 8, "recursive"), ("C5", 8192, 10, "batch_cp"),
                                                        ("C2", 4096, 10, "batch")])
-def test_full_size_properties(ctx, cfg_name, B, nb_iter, solver):
+def test_full_size_properties(ctx, cfg_name, B, nb_iter, solver, monkeypatch):
     from ilqr_planner_amd import workloads
+
+    if cfg_name == "C4":  # the sweep of the time systems is chosen by batch size (two kernels that agree to rounding): the bit-for-bit
+        monkeypatch.setenv("ILQR_SWEEP", "rows")  # comparison of the big batch with its cut-out is made on the one the big batch takes
 
     cfg = workloads.config(cfg_name)
     desc, inp = workloads.make_batch(ctx, cfg, B=B)
