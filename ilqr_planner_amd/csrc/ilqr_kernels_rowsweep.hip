@@ -73,28 +73,28 @@ __device__ __forceinline__ void rw_fmac(double* acc, const double* src, double m
 }
 
 // One pivot of the symmetric sweep with deferred row scaling on an NP-column row (NP = 7 or 8), pivot row in lane L (see ilqr_kernels_dpp.hip):
-//   acc = bcast_L(s[C]); rc = 1/acc; t = (s[C] + s[C] nm1) rc; s[j] -= t bcast_L(s[j]) (j != C); s[C] = t + nm1; myrc -= rc nm1
+//   acc = bcast_L(s[C]); rc = 1/acc; t = (s[C] - s[C] dc) rc; s[j] -= t bcast_L(s[j]) (j != C); s[C] = t - dc; myrc += rc dc   (dc = 1 in the pivot lane, 0 elsewhere)
 template <int NP, int C, int L>
-__device__ __forceinline__ void rw_pivot(double (&s)[8], double nm1, double& myrc) {
+__device__ __forceinline__ void rw_pivot(double (&s)[8], double dc, double& myrc) {
     double acc, rc, e, t;
     constexpr int J0 = (C == 0) ? 1 : 0, J1 = J0 + 1 + (C == J0 + 1), J2 = J1 + 1 + (C == J1 + 1), J3 = J2 + 1 + (C == J2 + 1), J4 = J3 + 1 + (C == J3 + 1),
                   J5 = J4 + 1 + (C == J4 + 1), J6 = J5 + 1 + (C == J5 + 1);  // the other columns in ascending order
 #define HEAD_                                                                                                  \
     "s_nop 1\n\tv_mov_b64_dpp %[acc], %[sc] row_newbcast:%[L]" RW_ALL_ "\n\t"                                    \
-    "v_rcp_f64 %[rc], %[acc]\n\tv_fma_f64 %[t], %[sc], %[n], %[sc]\n\tv_fma_f64 %[e], -%[acc], %[rc], 1.0\n\t"  \
+    "v_rcp_f64 %[rc], %[acc]\n\tv_fma_f64 %[t], %[sc], -%[n], %[sc]\n\tv_fma_f64 %[e], -%[acc], %[rc], 1.0\n\t" \
     "v_fma_f64 %[e], %[e], %[e], %[e]\n\tv_fma_f64 %[rc], %[e], %[rc], %[rc]\n\tv_mul_f64 %[t], %[t], %[rc]\n\t"
 #define F_(N) "v_fmac_f64_dpp %[s" #N "], %[s" #N "], -%[t] row_newbcast:%[L]" RW_ALL_ "\n\t"
-#define TAIL_ "v_add_f64 %[sc], %[t], %[n]\n\tv_fma_f64 %[myrc], -%[rc], %[n], %[myrc]"
+#define TAIL_ "v_add_f64 %[sc], %[t], -%[n]\n\tv_fma_f64 %[myrc], %[rc], %[n], %[myrc]"
     if (NP == 8)
         asm volatile(HEAD_ F_(0) F_(1) F_(2) F_(3) F_(4) F_(5) F_(6) TAIL_
                      : [acc] "=&v"(acc), [rc] "=&v"(rc), [e] "=&v"(e), [t] "=&v"(t), [sc] "+v"(s[C]), [s0] "+v"(s[J0]), [s1] "+v"(s[J1]), [s2] "+v"(s[J2]), [s3] "+v"(s[J3]),
                        [s4] "+v"(s[J4]), [s5] "+v"(s[J5]), [s6] "+v"(s[J6]), [myrc] "+v"(myrc)
-                     : [n] "v"(nm1), [L] "n"(L));
+                     : [n] "v"(dc), [L] "n"(L));
     else
         asm volatile(HEAD_ F_(0) F_(1) F_(2) F_(3) F_(4) F_(5) TAIL_
                      : [acc] "=&v"(acc), [rc] "=&v"(rc), [e] "=&v"(e), [t] "=&v"(t), [sc] "+v"(s[C]), [s0] "+v"(s[J0]), [s1] "+v"(s[J1]), [s2] "+v"(s[J2]), [s3] "+v"(s[J3]),
                        [s4] "+v"(s[J4]), [s5] "+v"(s[J5]), [myrc] "+v"(myrc)
-                     : [n] "v"(nm1), [L] "n"(L));
+                     : [n] "v"(dc), [L] "n"(L));
 #undef HEAD_
 #undef F_
 #undef TAIL_
@@ -138,8 +138,8 @@ __global__ __launch_bounds__(64) void k_backward_rows(Bufs a) {
     const double Rc = isC ? d.R_diag[ci] : 0.0;
     const bool wl = isX && d.lw[vx] != 0;
     const double mxl = wl ? d.smax[vx] : __builtin_inf(), mnl = wl ? d.smin[vx] : -__builtin_inf();
-    double dci[8], nm1[8];  // dci[k] = 1 in the lane of control row k; nm1 = -dci (the sweep's lane constant)
-    UNR for (int k = 0; k < 8; k++) { dci[k] = (isC && ci == k && k < NU) ? 1.0 : 0.0; nm1[k] = -dci[k]; }
+    double dci[8];  // dci[k] = 1 in the lane of control row k (also the sweep's lane constant)
+    UNR for (int k = 0; k < 8; k++) dci[k] = (isC && ci == k && k < NU) ? 1.0 : 0.0;
 
     // gain records of the wave's instances (adjacent in memory) leave as 16-byte pieces of an LDS image
     constexpr int PCS = RS / 2, NPQ = (IPW * PCS + 63) / 64;
@@ -319,14 +319,14 @@ __global__ __launch_bounds__(64) void k_backward_rows(Bufs a) {
         // ---- 4. Quu_inv = -(Quu + reg I)^-1: symmetric sweep with deferred row scaling; afterwards myrc * s = this lane's row of Quu_inv
         double s[8], myrc = 0.0;
         UNR for (int kk = 0; kk < 8; kk++) s[kk] = (kk < NU) ? fma(dci[kk], reg, quu[kk]) : 0.0;
-        rw_pivot<NU, 0, CLANE(0)>(s, nm1[0], myrc);
-        rw_pivot<NU, 1, CLANE(1)>(s, nm1[1], myrc);
-        rw_pivot<NU, 2, CLANE(2)>(s, nm1[2], myrc);
-        rw_pivot<NU, 3, CLANE(3)>(s, nm1[3], myrc);
-        rw_pivot<NU, 4, CLANE(4)>(s, nm1[4], myrc);
-        rw_pivot<NU, 5, CLANE(5)>(s, nm1[5], myrc);
-        rw_pivot<NU, 6, CLANE(6)>(s, nm1[6], myrc);
-        if (NU == 8) rw_pivot<NU, 7, CLANE(7)>(s, nm1[7], myrc);
+        rw_pivot<NU, 0, CLANE(0)>(s, dci[0], myrc);
+        rw_pivot<NU, 1, CLANE(1)>(s, dci[1], myrc);
+        rw_pivot<NU, 2, CLANE(2)>(s, dci[2], myrc);
+        rw_pivot<NU, 3, CLANE(3)>(s, dci[3], myrc);
+        rw_pivot<NU, 4, CLANE(4)>(s, dci[4], myrc);
+        rw_pivot<NU, 5, CLANE(5)>(s, dci[5], myrc);
+        rw_pivot<NU, 6, CLANE(6)>(s, dci[6], myrc);
+        if (NU == 8) rw_pivot<NU, 7, CLANE(7)>(s, dci[7], myrc);
         if (kprev) SEND_()
         // ---- 5. K~ = Quu_inv Qux~ (control lanes): sum_k s[k] (row of control k), scaled by myrc
         double Kt[16];

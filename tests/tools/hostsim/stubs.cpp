@@ -21,6 +21,8 @@ bool init_lti_supported(int, int) { return false; }
 void launch_solver_v2(int, int, int, bool, const Bufs&, int, int, hipStream_t, const FwdArgs&) { refuse("launch_solver_v2"); }
 void launch_backward_si_dpp(bool, bool, bool, int, const Bufs&, int, hipStream_t, const SweepArgs&) { refuse("k_backward_si_dpp"); }
 void launch_backward_mfma(int, int, bool, const Bufs&, int, hipStream_t) { refuse("k_backward_mfma"); }
+bool backward_rows_supported(int, int, bool, int) { return false; }
+void launch_backward_rows(int, int, bool, const Bufs&, int, hipStream_t) { refuse("k_backward_rows"); }
 void launch_apply_rows_tm(int, int, const Bufs&, int, hipStream_t, const FwdArgs&) { refuse("k_apply_rows_tm"); }
 void launch_forward_mfma(int, int, const Bufs&, int, hipStream_t, const FwdArgs&) { refuse("k_forward_mfma"); }
 void launch_forward_lin(int, int, const Bufs&, int, int, hipStream_t, const FwdArgs&) { refuse("k_forward_lin"); }
