@@ -27,7 +27,7 @@ struct ilqr_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     bool profile = false;
-    bool split = true;  // ilqr_ctx_set_split
+    int split = 1;  // ilqr_ctx_set_split: 0 off, 1 where it was measured to pay, 2 every cooperative path (experiments)
     double prof_ms[ILQR_PROF_COUNT] = {0, 0, 0, 0, 0};
     int prof_n[ILQR_PROF_COUNT] = {0, 0, 0, 0, 0};
     struct Pending { hipEvent_t a, b; int which; };
@@ -38,6 +38,7 @@ struct ilqr_ctx {
     int n_simd = 1024;  // SIMDs of the device (4 per CU)
     bool xc_generic = false, xc_cp_lane = false, xc_cp_general = false;  // cross-check kernel variants (ilqr_ctx_set_crosscheck)
     int xc_sweep = 0;  // sweep of the 2nd-order / time systems: 0 = by batch size, 1 = matrix-core sweep, 2 = row sweep
+    int xc_fwd = 0;    // forward pass of the single-integrator systems: 0 = by batch size, 1 = k_forward_wg (bandwidth), 2 = k_forward_dpp (latency)
     hipStream_t half_stream[2] = {nullptr, nullptr};
     hipEvent_t ev_begin = nullptr, ev_half_done[2] = {nullptr, nullptr}, ev_stagger = nullptr;
 };
@@ -158,13 +159,14 @@ extern "C" int ilqr_ctx_set_stream(ilqr_ctx* c, void* s) {
 
 extern "C" int ilqr_ctx_set_split(ilqr_ctx* c, int on) {
     if (!c) return 1;
-    c->split = on != 0;
+    c->split = on;
     return 0;
 }
 
 extern "C" int ilqr_ctx_set_crosscheck(ilqr_ctx* c, int generic_kernels, int cp_lane_solve, int cp_general, int mfma_sweep) {
     if (!c) return 1;
-    c->xc_sweep = (mfma_sweep == 1 || mfma_sweep == 2) ? mfma_sweep : 0;
+    c->xc_sweep = ((mfma_sweep & 3) == 1 || (mfma_sweep & 3) == 2) ? (mfma_sweep & 3) : 0;
+    c->xc_fwd = (((mfma_sweep >> 2) & 3) == 1 || ((mfma_sweep >> 2) & 3) == 2) ? ((mfma_sweep >> 2) & 3) : 0;
     c->xc_generic = generic_kernels != 0;
     c->xc_cp_lane = cp_lane_solve != 0;
     c->xc_cp_general = cp_general != 0;
@@ -614,7 +616,7 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
     // workgroups on 3072 wave slots otherwise leave a one-third-full second round), not for the single-integrator pipeline (C3: the forward
     // pass slows from 0.125 to 0.24 ms and k_kp_derivs from 0.017 to 0.08-0.14 ms when they share the SIMDs with the other half's sweep:
     // 0.53 ms per iteration against 0.49 unsplit).
-    const bool split = coop && bwd_mfma && !bwd_rows && c->split && !c->profile && p->ddesc_half[0] && nb_iter > 0;
+    const bool split = coop && ((bwd_mfma && !bwd_rows && c->split) || c->split == 2) && !c->profile && p->ddesc_half[0] && nb_iter > 0;
     if (!bwd_si && !bwd_mfma && nb_iter > 0 && !p->bufs.ws)  // the generic sweep keeps the matrices of a step in an explicit workspace
         if (dalloc(p, &p->bufs.ws, (size_t)backward_ws_entries(kind, nd) * p->Bp, false)) return 1;
     if (split) {
@@ -649,6 +651,9 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
     std::memset(&f, 0, sizeof(f));
     f.line_search = line_search; f.early_stop = early_stop; f.nb_iter = nb_iter; f.penalty_roll = penalty0; f.n_alpha = n_alpha; f.al = al ? 1 : 0; f.n_kp = p->desc.n_kp;
     f.fused = fused ? 1 : 0;
+    f.limits = p->desc.limits_set ? 1 : 0;
+    // small batches (at most FWD_SMALL_WAVES_PER_SIMD waves of 4 instances per SIMD): the rollout is a chain, not a stream -- k_forward_dpp
+    f.small = (fwd_wave && c->xc_fwd != 1 && (c->xc_fwd == 2 || (p->B + 3) / 4 <= c->n_simd / 2)) ? 1 : 0;
     for (int k = 0; k < p->desc.n_kp; k++) f.kp_ext |= p->desc.kp_dist[k] | p->desc.kp_has_frame[k] | p->desc.kp_has_Ru[k] | p->desc.kp_joint[k];
     for (int h = 0; h < nh; h++) {
         const Bufs& bf = hv[h].bufs;

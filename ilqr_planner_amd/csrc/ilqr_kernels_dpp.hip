@@ -151,6 +151,15 @@ __device__ __forceinline__ double oct_sum(double v) {  // sum over lanes 8m .. 8
 }
 
 __device__ __forceinline__ double ldg(const double* base, unsigned byte_off) { return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + byte_off); }
+// A ring value moved out of its slot by an instruction the compiler cannot fold away: the slot register is then free BEFORE the slot's next
+// load is issued, the loop-carried value and the load destination share one register, and no copy is left on the back edge.  (Without it
+// the old value stayed in place for the whole step, the new load went to a second register, and the copies that rotate the ring at the
+// end of the unrolled group waited for the loads issued ONE step earlier: s_waitcnt vmcnt(4) .. vmcnt(0) once per group.)
+__device__ __forceinline__ double ring_take(double v) {
+    double r;
+    asm volatile("v_mov_b64_e32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
 __device__ __forceinline__ void stg(double* base, unsigned byte_off, double v) { *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + byte_off) = v; }
 
 }  // namespace
@@ -293,13 +302,18 @@ __global__ __launch_bounds__(64) void k_backward_si_dpp(Bufs a, SweepArgs sw) {
     for (int k0 = T - 2; k0 >= 0; k0 -= PF) {
       UNR for (int jj = 0; jj < PF; jj++) {
         const int k = k0 - jj;
-        double xv = xr[jj], uv = ur[jj];
+        double xv = ring_take(xr[jj]), uv = ring_take(ur[jj]);
         if (FUSED) {  // accepted trajectory (k_apply's expression)
-            xv = fma(aacc, x1r[jj] - xv, xv);
-            uv = fma(aacc, u1r[jj] - uv, uv);
+            const double x1v = ring_take(x1r[jj]), u1v = ring_take(u1r[jj]);
+            xv = fma(aacc, x1v - xv, xv);
+            uv = fma(aacc, u1v - uv, uv);
         }
         double lam[MRR], Isk[MRR];
-        UNR for (int rr = 0; rr < MRR; rr++) { lam[rr] = lr[jj][rr]; Isk[rr] = ir[jj][rr]; }
+        UNR for (int rr = 0; rr < MRR; rr++) {
+            lam[rr] = (MR > 0) ? ring_take(lr[jj][rr]) : 0.0;
+            Isk[rr] = (MR > 0 && !FUSED) ? ring_take(ir[jj][rr]) : ir[jj][rr];
+        }
+        __builtin_amdgcn_sched_barrier(0);  // the slots are free: only now their next loads
         fetch(jj, k - PF);
         // the image of the step before this one (in time) leaves now: LDS -> registers here, registers -> memory after the pivots
         const bool kprev = k < T - 2;

@@ -54,6 +54,12 @@ __device__ __forceinline__ double rw_row_sum(double v) {  // sum over the 16 lan
     return v;
 }
 
+__device__ __forceinline__ double rw_take(double v) {
+    double r;
+    asm volatile("v_mov_b64_e32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+
 // acc[c] += bcast_L(src[c]) * mul for N consecutive columns starting at acc / src (N = 8, 7 or 1): one statement, two wait states first
 template <int L, int N>
 __device__ __forceinline__ void rw_fmac(double* acc, const double* src, double mul) {
@@ -112,8 +118,11 @@ __global__ __launch_bounds__(64) void k_backward_rows(Bufs a) {
     constexpr int MMAX = 16;
     static_assert(NX <= 15 && NX >= 8 && NU <= 8 && (H1 == 1 || H1 == 7 || H1 == 8), "row halves of 8 + {1, 7, 8} columns");
 #define CLANE(k) (((k) < DOF) ? CB + (k) : 15)  // DPP lane that holds control row k
-    __shared__ __attribute__((aligned(16))) double sKT[IPW][NU][16];        // K~ of the step, for its transposition
-    __shared__ __attribute__((aligned(16))) double sK[2][IPW * RS + 64];    // two images of the wave's gain records
+    // LDS rows are ROWP + 2 doubles apart: the control lanes of a wave write 16-byte pieces of their rows at the same column, and at a stride of
+    // 128 bytes all of them fall on the same four banks (measured: bank conflicts were 69 % of the LDS cycles of the first version)
+    constexpr int RSTR = ROWP + 2, KSTR = 18;
+    __shared__ __attribute__((aligned(16))) double sKT[IPW][NU][KSTR];          // K~ of the step, for its transposition
+    __shared__ __attribute__((aligned(16))) double sK[2][IPW * NU * RSTR];      // two images of the wave's gain records (rows padded)
     const DevDesc& d = *a.desc;
     const int lane = threadIdx.x, g = lane >> 4, l = lane & 15;
     const int b = xcd_tile() * IPW + g;
@@ -142,14 +151,16 @@ __global__ __launch_bounds__(64) void k_backward_rows(Bufs a) {
     UNR for (int k = 0; k < 8; k++) dci[k] = (isC && ci == k && k < NU) ? 1.0 : 0.0;
 
     // gain records of the wave's instances (adjacent in memory) leave as 16-byte pieces of an LDS image
-    constexpr int PCS = RS / 2, NPQ = (IPW * PCS + 63) / 64;
-    static_assert(RS % 2 == 0 && (IPW * RS + 64) * 8 >= 64 * NPQ * 16, "image read stays inside the array");
+    constexpr int PCS = RS / 2, RPC = ROWP / 2, NPQ = (IPW * PCS + 63) / 64;  // pieces per record / per row; pieces of the wave per lane
+    static_assert(RS % 2 == 0 && ROWP % 2 == 0, "16-byte pieces");
     const unsigned long long okm = __ballot(ok ? 1 : 0);
     const bool kfull = okm == ~0ull;
     bool pst[NPQ];
+    int pof[NPQ];  // where piece lane + 64 q of the linear image lies in the padded one (doubles)
     UNR for (int q = 0; q < NPQ; q++) {
-        const int c = lane + 64 * q, gi = (c / PCS < IPW) ? c / PCS : 0;
+        const int c = lane + 64 * q, cc = (c < IPW * PCS) ? c : IPW * PCS - 1, gi = cc / PCS, rw = (cc % PCS) / RPC, jp = cc % RPC;
         pst[q] = c < IPW * PCS && ((okm >> (gi * 16)) & 1ull);
+        pof[q] = (gi * NU + rw) * RSTR + 2 * jp;
     }
     double* Kout = KD_REC(a.KD, Bp, RS, T - 2, xcd_tile() * IPW);
     const ptrdiff_t Kstep = (ptrdiff_t)Bp * RS;
@@ -208,14 +219,16 @@ __global__ __launch_bounds__(64) void k_backward_rows(Bufs a) {
     for (int k0 = T - 2; k0 >= 0; k0 -= PF) {
       UNR for (int jj = 0; jj < PF; jj++) {
         const int k = k0 - jj;
-        const double xv = xm * xr[jj], uv = (isC ? 1.0 : 0.0) * ur[jj], lamv = lmr[jj], isv = isr[jj];
+        // (ring values leave their slots by an opaque move before the slot's next load is issued: see ring_take in ilqr_kernels_dpp.hip)
+        const double xv = xm * rw_take(xr[jj]), uv = (isC ? 1.0 : 0.0) * rw_take(ur[jj]), lamv = AL ? rw_take(lmr[jj]) : 0.0, isv = AL ? rw_take(isr[jj]) : 0.0;
+        __builtin_amdgcn_sched_barrier(0);
         fetch(jj, k - PF);
         // the gain image of the step before this one (in time) leaves now: LDS -> registers here, registers -> memory after the pivots
         const bool kprev = k < T - 2;
         const int ib = (T - 2 - k) & 1;  // image written by this step; the previous step wrote the other one
         double kqa[NPQ], kqb[NPQ];
         UNR for (int q = 0; q < NPQ; q++) {
-            const double2 t2 = reinterpret_cast<const double2*>(sK[ib ^ 1])[lane + 64 * q];
+            const double2 t2 = *reinterpret_cast<const double2*>(&sK[ib ^ 1][pof[q]]);
             kqa[q] = t2.x; kqb[q] = t2.y;
         }
 #define SEND_()                                                                                                         \
@@ -342,7 +355,7 @@ __global__ __launch_bounds__(64) void k_backward_rows(Bufs a) {
         BLK_ALL_(Kt, Qux, sm)
         // ---- gains out (the lane's row {K_i0 .. K_i,nx-1, d_i} is ROWP contiguous doubles of the record) + the image for the transposition
         if (isC) {
-            double* w = &sK[ib][g * RS + ci * ROWP];
+            double* w = &sK[ib][(g * NU + ci) * RSTR];
             UNR for (int c = 0; c + 1 < ROWP; c += 2) *reinterpret_cast<double2*>(w + c) = make_double2(Kt[c], (c + 1 < NC) ? Kt[c + 1] : 0.0);
             double* wt = &sKT[g][ci][0];
             UNR for (int c = 0; c < 16; c += 2) *reinterpret_cast<double2*>(wt + c) = make_double2(Kt[c], Kt[c + 1]);
@@ -365,7 +378,7 @@ __global__ __launch_bounds__(64) void k_backward_rows(Bufs a) {
     }
     if ((T - 2) % PF == PF - 1) {  // the last real step closed its group: no dummy step sent its image out
         const int ib = (T - 2) & 1;
-        UNR for (int q = 0; q < NPQ; q++) if (pst[q]) reinterpret_cast<double2*>(Kout + Kstep)[lane + 64 * q] = reinterpret_cast<const double2*>(sK[ib])[lane + 64 * q];
+        UNR for (int q = 0; q < NPQ; q++) if (pst[q]) reinterpret_cast<double2*>(Kout + Kstep)[lane + 64 * q] = *reinterpret_cast<const double2*>(&sK[ib][pof[q]]);
     }
 #undef SEND_
 #undef CLANE

@@ -256,6 +256,191 @@ __global__ __launch_bounds__(FW_IW * 32) void k_forward_wg(Bufs a, FwdArgs f) {
     if (colst && jl == 0) a.dun[bb] = dun;
 }
 
+
+// ------------------------------------------------------------------------------------------------ small batches
+// k_forward_wg is built for bandwidth: 32 lanes and an LDS round trip per instance-step, two workgroup barriers per 8 steps -- 0.47 us per
+// step whatever the batch, 47 us of a 147 us iteration at B = 256 (BASELINE configs[1]).  At one wave per SIMD or less the rollout is a bare
+// chain, so this version makes the chain short: 16 lanes per instance as in the sweep (ilqr_kernels_dpp.hip), no LDS, no workgroup.
+//   lane (h, r), h = half of the 16-lane row, r = gain row / coordinate:  half 0 holds {K_r0 .. K_r3} and forms K_r0 dx_0 + .. + K_r3 dx_3, half 1 holds
+//   {K_r4, K_r5, K_r6, d_r} and forms K_r4 dx_4 + .. + d_r; dx_c comes straight out of lane c's register as the `row_newbcast` operand of
+//   `v_fmac_f64_dpp`; the halves meet by one `row_ror:8` move, so both hold du_r and both advance dx_r += dt du_r.
+//   Memory: a wave may have 64 vector-memory instructions in flight, so what bounds the chain is instructions per step x latency / 64 (measured with
+//   8 per step: 0.23 us per step at any ring depth).  Hence 4 per step: the gain row as two 16-byte loads per lane (the halves take the two halves of
+//   the row), xbar_r | ubar_r as ONE load (half 0 / half 1), x(1)_r | u(1)_r as ONE store.  Ring of PF = 14 steps; a slot is refilled after its last
+//   use, so the loop-carried value and the load share a register (see ring_take in ilqr_kernels_dpp.hip for what happens otherwise).
+// Outputs as k_forward_wg: x(1), u(1) into the other buffer, (dx, du) at the keypoint steps, the limit cost of every step size, sum ||du||.
+// (Measured and dropped: this kernel, the decision and the next sweep's keypoint derivatives as ONE launch, a wave carrying its four instances through the
+// three phases -- bit-identical, and no faster at any batch size (C2, B = 256: 2.472 against 2.463 ms per solve): what the two launches cost is made up
+// by k_select's two waves per instance group, which the one-wave form cannot have.)
+#define FD_LO " row_mask:0xf bank_mask:0x3"
+#define FD_HI " row_mask:0xf bank_mask:0xc"
+// this half's part of du_r = d_r + sum_c K_rc dx_c (see above); three accumulators in rotation: a DPP instruction reads its accumulator early, no
+// register is touched again within two instructions
+__device__ __forceinline__ double fd_half_dot(const double (&K)[4], double x, double one) {
+    double s0, s1, s2;
+#define D_(A, J, C, M, X) "v_fmac_f64_dpp %[" A "], %[" X "], %[k" #J "] row_newbcast:" #C M "\n\t"
+    asm volatile("v_mov_b64 %[s0], 0\n\tv_mov_b64 %[s1], 0\n\tv_mov_b64 %[s2], 0\n\ts_nop 1\n\t"
+                 D_("s0", 0, 0, FD_LO, "x") D_("s1", 1, 1, FD_LO, "x") D_("s2", 2, 2, FD_LO, "x") D_("s0", 0, 4, FD_HI, "x") D_("s1", 1, 5, FD_HI, "x") D_("s2", 2, 6, FD_HI, "x")
+                 D_("s0", 3, 3, FD_LO, "x") D_("s1", 3, 0, FD_HI, "one") "s_nop 0"
+                 : [s0] "=&v"(s0), [s1] "=&v"(s1), [s2] "=&v"(s2)
+                 : [x] "v"(x), [one] "v"(one), [k0] "v"(K[0]), [k1] "v"(K[1]), [k2] "v"(K[2]), [k3] "v"(K[3]));
+#undef D_
+    return (s0 + s1) + s2;
+}
+// sum over lanes 8m .. 8m+7, result in all eight (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror)
+__device__ __forceinline__ double fd_oct_sum(double v) {
+    v += dpp_f64<0xB1>(v);
+    v += dpp_f64<0x4E>(v);
+    v += dpp_f64<0x141>(v);
+    return v;
+}
+
+// LIM / ES: limits set / early stop asked for -- template parameters because a branch instruction costs a lone wave 20-30 clocks whether taken or not
+// (probe build/exp/lat.hip: the 22-instruction chain of a step takes 89 clocks, the first version of this loop 530 with its six branches per step).
+// For the same reason a group of PF steps that holds no keypoint step and does not reach the end of the horizon runs a copy of the body without
+// those two tests.
+template <int NA, bool LIM, bool ES>
+__device__ __forceinline__ bool forward_dpp_body(const Bufs& a, const FwdArgs& f) {  // false: no running instance in this wave
+    constexpr int NX = 7, NU = 7, ROWP = kd_rowp(NX), RS = NU * ROWP, PF = 8;
+    static_assert(ROWP == 8, "record row = 7 gains + feed-forward");
+    const DevDesc& d = *a.desc;
+    const int lane = threadIdx.x, g = lane >> 4, l = lane & 15, h = l >> 3, r8 = l & 7;
+    const int b = xcd_tile() * 4 + g;
+    const int Bp = d.Bp, T = d.T, B = d.B;
+    const bool inst_ok = (b < B) && (a.active[b < B ? b : 0] != 0);
+    if (__ballot(inst_ok ? 1 : 0) == 0ull) return false;  // wave-uniform
+    const int bb = (b < B) ? b : 0;
+    const bool row = r8 < NX;              // lanes (h, 7) shadow row 6: never store, never the source of a broadcast
+    const int r = row ? r8 : NX - 1;
+    const bool st = inst_ok && row;        // this lane stores (x in half 0, u in half 1)
+    const bool sx = st && h == 0;          // ... and holds a state coordinate
+    const int cur = a.cur[bb];
+    const double dt = d.dt, pen = d.penalty, one = 1.0;
+    const int lw = LIM ? d.lw[r] : 0;
+    const double mx = lw ? d.smax[r] : INFINITY, mn = lw ? d.smin[r] : -INFINITY;
+    const int n_kp = d.n_kp;
+    int kpi = 0, kp_next = (n_kp > 0) ? d.kp_t[0] : -1;
+
+    const size_t Vstep = (size_t)NX * Bp, Kstep = (size_t)Bp * RS;
+    const double* pV = (h ? a.U[cur] : a.X[cur]) + (size_t)r * Bp + bb;      // xbar_r (half 0) | ubar_r (half 1): same stride
+    const double* pK = a.KD + (size_t)bb * RS + r * ROWP + 4 * h;             // this half's 32 bytes of the row
+    double* qV = (h ? a.U[1 - cur] : a.X[1 - cur]) + (size_t)r * Bp + bb;
+    const double xT = a.X[cur][((size_t)(T - 1) * NX + r) * Bp + bb];         // terminal xbar
+
+    double Kr[PF][4], vr[PF];
+    auto fetch = [&](int slot, int kk) {  // unconditional; the pointers stop at the last control step
+        const double2* k2 = reinterpret_cast<const double2*>(pK);
+        const double2 v0 = k2[0], v1 = k2[1];
+        Kr[slot][0] = v0.x; Kr[slot][1] = v0.y; Kr[slot][2] = v1.x; Kr[slot][3] = v1.y;
+        vr[slot] = *pV;
+        const bool more = kk < T - 2;  // uniform: a scalar select, not a branch
+        pK += more ? Kstep : 0; pV += more ? Vstep : 0;
+    };
+    UNR for (int q = 0; q < PF; q++) { fetch(q, q); __builtin_amdgcn_sched_barrier(0); }
+
+    double dx = 0, dun = 0, pc[NA];
+    UNR for (int i = 0; i < NA; i++) pc[i] = 0;
+    // inspectJointLimit on one coordinate (System.cpp:163-179), branch-free as in k_forward_wg
+    auto limit_cost_of = [&](double v) -> double {
+        const double q = fmax(v - mx, 0.0) + fmax(mn - v, 0.0);
+        return q * pen * q;
+    };
+    auto limits_all = [&](double xb) {  // the stage's limit cost of this coordinate for every step size
+        UNR for (int i = 0; i < NA; i++) pc[i] += limit_cost_of(fma(ldexp(1.0, -i), dx, xb));
+    };
+    auto seg_bad = [&](double xb) -> bool {  // the segment [xbar, x(1)] of this coordinate leaves [mn, mx]
+        const double e = xb + dx;
+        return (fmax(xb, e) > mx) | (fmin(xb, e) < mn);
+    };
+    double* kpdev = a.kpdev;
+
+#define FD_STEP_(JJ, CHK)                                                                                          \
+    {                                                                                                              \
+        const int k = k0 + JJ;                                                                                     \
+        if (!CHK || k < T - 1) {                                                                                   \
+            const double vb = vr[JJ];                        /* xbar_r | ubar_r */                                 \
+            const double part = fd_half_dot(Kr[JJ], dx, one);                                                      \
+            const double du = part + dpp_f64<0x128>(part);   /* row_ror:8: the other half's part */                \
+            if (st) *qV = vb + (h ? du : dx);                                                                      \
+            qV += Vstep;                                                                                           \
+            if (ES) dun += __builtin_amdgcn_sqrt(fd_oct_sum(row ? du * du : 0.0));   /* ||du_k(1)|| */             \
+            if (LIM && __builtin_expect(__ballot((seg_bad(vb) & sx) ? 1 : 0) != 0ull, 0)) limits_all(vb);          \
+            if (CHK && k == kp_next) {   /* hand the deviation of this step to k_select */                         \
+                double* o = kpdev + (size_t)kpi * (NX + NU) * Bp;                                                  \
+                if (st) AT(o, h * NX + r, bb) = h ? du : dx;                                                       \
+                kpi++;                                                                                             \
+                kp_next = (kpi < n_kp) ? __builtin_amdgcn_readfirstlane(d.kp_t[kpi]) : -1;                         \
+            }                                                                                                      \
+            dx = dx + dt * du;   /* deviation dynamics (both halves) */                                            \
+        }                                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);   /* the slot is free: only now its next load */                        \
+        fetch(JJ, k + PF);                                                                                         \
+    }
+    for (int k0 = 0; k0 < T - 1; k0 += PF) {
+        const bool plain = (k0 + PF <= T - 1) && (kp_next < 0 || kp_next >= k0 + PF);  // uniform
+        if (plain) {
+            FD_STEP_(0, false) FD_STEP_(1, false) FD_STEP_(2, false) FD_STEP_(3, false) FD_STEP_(4, false) FD_STEP_(5, false) FD_STEP_(6, false) FD_STEP_(7, false)
+        } else {
+            FD_STEP_(0, true) FD_STEP_(1, true) FD_STEP_(2, true) FD_STEP_(3, true) FD_STEP_(4, true) FD_STEP_(5, true) FD_STEP_(6, true) FD_STEP_(7, true)
+        }
+    }
+#undef FD_STEP_
+    static_assert(PF == 8, "eight step copies above");
+    {   // terminal state
+        if (sx) *qV = xT + dx;
+        if (LIM && __ballot((seg_bad(xT) & sx) ? 1 : 0) != 0ull) limits_all(xT);
+        if (kp_next == T - 1 && sx) {
+            double* o = kpdev + (size_t)kpi * (NX + NU) * Bp;
+            AT(o, r, bb) = dx;
+        }
+    }
+    // limit cost per step size: the seven coordinates of an instance (half 0), lane 0 writes
+    UNR for (int i = 0; i < NA; i++) {
+        const double sA = LIM ? fd_oct_sum(row ? pc[i] : 0.0) : 0.0;
+        if (inst_ok && l == 0) AT(a.lsc, i, bb) = sA;
+    }
+    if (inst_ok && l == 0) a.dun[bb] = dun;
+    return true;
+}
+template <int NA, bool LIM, bool ES>
+__global__ __launch_bounds__(64) void k_forward_dpp(Bufs a, FwdArgs f) { (void)forward_dpp_body<NA, LIM, ES>(a, f); }
+#undef FD_LO
+#undef FD_HI
+
+// The decision of k_select once every lane holds the task cost of its step size: limit cost added, the first step size (descending) below the current
+// cost wins, else the last one tried (ILQRRecursive.cpp:101-155); bookkeeping by the instance's first lane.  Returns the winner's index (uniform over
+// the instance's 16 lanes); *stopped = the instance left the iteration (early stop).
+template <int NA>
+__device__ __forceinline__ int select_decide(const Bufs& a, const FwdArgs& f, const DevDesc& d, int bb, bool inst_ok, bool mine, int gi, int al, int n_alpha, double c,
+                                             bool* stopped = nullptr) {
+    const int Bp = d.Bp;
+    if (mine) c += AT(a.lsc, al, bb);
+    const double cost0 = a.cost[bb];
+    const bool okc = mine && !((c >= cost0) || isnan(c));
+    const unsigned m16 = (unsigned)((__ballot(okc ? 1 : 0) >> (gi * 16)) & 0xffffull);
+    const int w = m16 ? (__ffs(m16) - 1) : (n_alpha - 1);
+    const double wcost = __shfl(c, gi * 16 + w);
+    bool stop = false;
+    if (inst_ok && al == 0) {
+        const double walpha = ldexp(1.0, -w);
+        a.cost[bb] = wcost;
+        a.alpha[bb] = walpha;
+        a.iters[bb] = f.it + 1;
+        a.status[bb] = (isfinite(wcost) ? 0 : 1) | ((walpha <= d.alpha_floor) ? 2 : 0);
+        if (a.cost_trace) {
+            a.cost_trace[(size_t)f.it * Bp + bb] = wcost;
+            a.alpha_trace[(size_t)f.it * Bp + bb] = walpha;
+        }
+        a.pend[bb] = w + 1;  // k_blend / k_flip finish the acceptance (w == 0: the buffer already holds x(1), u(1))
+        a.pred[bb] = w;
+        stop = f.early_stop && (walpha * sqrt(walpha * a.dun[bb]) < d.stop_tol);  // sum ||du(alpha)|| = alpha sum ||du(1)||
+        if (!f.al) stop = stop && (wcost < 1e-3);  // ILQRRecursive.cpp:174 vs AL-ILQR.cpp:225
+        if (stop) a.active[bb] = 0;
+    }
+    if (stopped) *stopped = __shfl(stop ? 1 : 0, gi * 16) != 0;
+    return w;
+}
+
 // Line-search decision of iteration f.it, one lane per (instance, alpha): task cost of x(alpha) = xbar + alpha dx at the keypoint
 // steps + the limit cost k_forward_w32 accumulated; the first alpha (descending) whose cost is below the current one wins, else
 // the last one tried (ILQRRecursive.cpp:101-155).  Writes cost/alpha/iters/status/traces, `pend` for k_blend/k_flip, and the
@@ -299,28 +484,7 @@ __global__ __launch_bounds__(64 * KW) void k_select(Bufs a, FwdArgs f) {
         if (wv != 0) return;
         if (mine) { for (int kpi = 0; kpi < d.n_kp; kpi++) c += sc[kpi][lane]; }
     }
-    if (mine) c += AT(a.lsc, al, bb);
-    const double cost0 = a.cost[bb];
-    const bool okc = mine && !((c >= cost0) || isnan(c));
-    const unsigned m16 = (unsigned)((__ballot(okc ? 1 : 0) >> (gi * 16)) & 0xffffull);
-    const int w = m16 ? (__ffs(m16) - 1) : (n_alpha - 1);
-    const double wcost = __shfl(c, gi * 16 + w);
-    if (inst_ok && al == 0) {
-        const double walpha = ldexp(1.0, -w);
-        a.cost[bb] = wcost;
-        a.alpha[bb] = walpha;
-        a.iters[bb] = f.it + 1;
-        a.status[bb] = (isfinite(wcost) ? 0 : 1) | ((walpha <= d.alpha_floor) ? 2 : 0);
-        if (a.cost_trace) {
-            a.cost_trace[(size_t)f.it * Bp + bb] = wcost;
-            a.alpha_trace[(size_t)f.it * Bp + bb] = walpha;
-        }
-        a.pend[bb] = w + 1;  // k_blend / k_flip finish the acceptance (w == 0: the buffer already holds x(1), u(1))
-        a.pred[bb] = w;
-        bool stop = f.early_stop && (walpha * sqrt(walpha * a.dun[bb]) < d.stop_tol);  // sum ||du(alpha)|| = alpha sum ||du(1)||
-        if (!f.al) stop = stop && (wcost < 1e-3);  // ILQRRecursive.cpp:174 vs AL-ILQR.cpp:225
-        if (stop) a.active[bb] = 0;
-    }
+    (void)select_decide<NA>(a, f, d, bb, inst_ok, mine, gi, al, n_alpha, c);
 }
 
 // Accepted trajectory + AL bookkeeping in one pass (k_blend and k_al_post each re-read the trajectory): one thread per
@@ -514,18 +678,33 @@ static void launch_select(const Bufs& a, int B, hipStream_t st, const FwdArgs& f
         else hipLaunchKernelGGL((k_select<S, NA, false, 1>), sgrid, dim3(64), 0, st, a, f);
     }
 }
+template <int NA>
+static void launch_forward_dpp(const Bufs& a, dim3 grid, hipStream_t st, const FwdArgs& f) {
+    const dim3 block(64);
+    if (f.limits) {
+        if (f.early_stop) hipLaunchKernelGGL((k_forward_dpp<NA, true, true>), grid, block, 0, st, a, f);
+        else hipLaunchKernelGGL((k_forward_dpp<NA, true, false>), grid, block, 0, st, a, f);
+    } else {
+        if (f.early_stop) hipLaunchKernelGGL((k_forward_dpp<NA, false, true>), grid, block, 0, st, a, f);
+        else hipLaunchKernelGGL((k_forward_dpp<NA, false, false>), grid, block, 0, st, a, f);
+    }
+}
 // the rollout itself knows no keypoint function (single-integrator dynamics); the decision kernel is per system kind
 template <class S>
 static void launch_forward_wave_sys(const Bufs& a, int B, hipStream_t st, const FwdArgs& f) {
     const dim3 grid(grid_x8((B + FW_IW - 1) / FW_IW)), block(FW_IW * 32);
+    const dim3 sgrid(grid_x8((B + 3) / 4));  // small batches: 16 lanes per instance, one wave per workgroup (k_forward_dpp)
     if (f.n_alpha <= 1) {
-        hipLaunchKernelGGL((k_forward_wg<1>), grid, block, 0, st, a, f);
+        if (f.small) launch_forward_dpp<1>(a, sgrid, st, f);
+        else hipLaunchKernelGGL((k_forward_wg<1>), grid, block, 0, st, a, f);
         launch_select<S, 1>(a, B, st, f);
     } else if (f.n_alpha <= 11) {
-        hipLaunchKernelGGL((k_forward_wg<11>), grid, block, 0, st, a, f);
+        if (f.small) launch_forward_dpp<11>(a, sgrid, st, f);
+        else hipLaunchKernelGGL((k_forward_wg<11>), grid, block, 0, st, a, f);
         launch_select<S, 11>(a, B, st, f);
     } else {
-        hipLaunchKernelGGL((k_forward_wg<16>), grid, block, 0, st, a, f);
+        if (f.small) launch_forward_dpp<16>(a, sgrid, st, f);
+        else hipLaunchKernelGGL((k_forward_wg<16>), grid, block, 0, st, a, f);
         launch_select<S, 16>(a, B, st, f);
     }
 }

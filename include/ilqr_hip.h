@@ -157,8 +157,9 @@ int ilqr_ctx_set_split(ilqr_ctx* ctx, int on);
  * set instead of the cooperative one; cp_lane_solve = 1 solves the Batch-CP normal equations with one lane per instance instead of one wave;
  * cp_general = 1 sends Batch-CP on the constant-dt systems through the general path of the time systems; mfma_sweep selects the backward sweep of
  * the 2nd-order / time systems: 0 = by batch size (one instance per wave on the f64 matrix cores up to two waves per SIMD, 16 lanes per instance
- * with rows in registers beyond), 1 = always the former, 2 = always the latter (the two agree to rounding, not bit for bit).
- * All 0 = the product path. */
+ * with rows in registers beyond), 1 = always the former, 2 = always the latter (the two agree to rounding, not bit for bit); its bits 2-3 select
+ * the forward pass of the single-integrator systems the same way (0 = by batch size, 4 = the bandwidth-built k_forward_wg, 8 = the
+ * latency-built k_forward_dpp).  All 0 = the product path. */
 int ilqr_ctx_set_crosscheck(ilqr_ctx* ctx, int generic_kernels, int cp_lane_solve, int cp_general, int mfma_sweep);
 const char* ilqr_version(void);
 

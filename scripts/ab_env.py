@@ -23,8 +23,12 @@ for B in [int(b) for b in os.environ.get("B", str(cfg["B"])).split(",")]:
                 workloads.run_solver(p, cfg, nb_iter=10, early_stop=False)
                 ctx.synchronize()
             ctx.profile(False)
-            ms, k = ctx.profile_get(1)
-            res[name].append(round(ms / k * 1e3, 1))
+            cats = [int(c) for c in os.environ.get("CATS", "1").split(",")]  # profile categories (capi.PROF_*): 1 = backward sweep, 2 = forward, 4 = other
+            vals = []
+            for cat in cats:
+                ms, k = ctx.profile_get(cat)
+                vals.append(round(ms / max(k, 1) * 1e3, 1))
+            res[name].append(vals[0] if len(vals) == 1 else vals)
             for kv in filter(None, env.split(";")):
                 os.environ.pop(kv.split("=")[0], None)
     print(B, json.dumps(res), "cost", float(p.cost()[:8].sum()), flush=True)

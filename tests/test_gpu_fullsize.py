@@ -60,6 +60,8 @@ def test_full_size_properties(ctx, cfg_name, B, nb_iter, solver, monkeypatch):
 
     if cfg_name == "C4":  # the sweep of the time systems is chosen by batch size (two kernels that agree to rounding): the bit-for-bit
         monkeypatch.setenv("ILQR_SWEEP", "rows")  # comparison of the big batch with its cut-out is made on the one the big batch takes
+    if cfg_name == "C3":  # likewise the forward pass of the single-integrator systems (k_forward_wg at this size, k_forward_dpp for small batches)
+        monkeypatch.setenv("ILQR_FWD", "wg")
 
     cfg = workloads.config(cfg_name)
     desc, inp = workloads.make_batch(ctx, cfg, B=B)
@@ -135,8 +137,29 @@ def test_full_size_properties(ctx, cfg_name, B, nb_iter, solver, monkeypatch):
         assert not failures, f"{len(failures)} instance(s) neither within 1e-4 nor proven: {failures[:3]}"
 
 
+@pytest.mark.parametrize("cfg_name,solver,B", [("C3", "al", 2048), ("C2", "recursive", 256), ("C2", "recursive", 1001)])
+def test_forward_passes_agree(ctx, cfg_name, solver, B, monkeypatch):
+    """The single-integrator systems have two forward passes chosen by batch size: k_forward_dpp (16 lanes per instance on registers: the chain of a
+    small batch) and k_forward_wg (32 lanes per instance through LDS: the stream of a large one).  They sum the seven products of a control in a
+    different order, so one iteration from the same state agrees to rounding, not bit for bit; each goes through the per-instance proof in
+    test_gpu_parity.py (hip_path v2 / v2wg).  Here: ONE iteration of both on the same batch -- trajectories to 1e-12, the same step sizes, costs to 1e-12."""
+    from ilqr_planner_amd import workloads
+
+    cfg = dict(workloads.config(cfg_name), T=60)
+    desc, inp = workloads.make_batch(ctx, cfg, B=B)
+    res = {}
+    for fwd in ("wg", "dpp"):
+        monkeypatch.setenv("ILQR_FWD", fwd)
+        res[fwd] = _solve(ctx, cfg, desc, inp, B, 1, solver)
+    a, b = res["wg"], res["dpp"]
+    np.testing.assert_array_equal(a["alpha"], b["alpha"])
+    np.testing.assert_allclose(b["cost"], a["cost"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(b["U"], a["U"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(b["X"], a["X"], rtol=0, atol=1e-11)
+
+
 @pytest.mark.parametrize("cfg_name,solver", [("C3", "al"), ("C2", "recursive")])
-def test_sweep_lane_groupings_agree(ctx, cfg_name, solver):
+def test_sweep_lane_groupings_agree(ctx, cfg_name, solver, monkeypatch):
     """The register-resident sweep of the single-integrator systems runs with 16 lanes per instance while that gives every SIMD at most one
     wave and with 8 lanes per instance (two instances per DPP row, every broadcast issued once per half with a bank mask) beyond: a batch
     just over 4 x 1024 instances takes the second form, a 61-instance cut-out of it the first.  Same operations on the same operands in the
@@ -145,6 +168,7 @@ def test_sweep_lane_groupings_agree(ctx, cfg_name, solver):
     from ilqr_planner_amd import workloads
     from tests import parity_proof as pp
 
+    monkeypatch.setenv("ILQR_FWD", "wg")  # the forward pass is chosen by batch size too (two kernels that agree to rounding): the big batch's one for both
     cfg = dict(workloads.config(cfg_name), T=40)
     B, nb_iter = 4200, 6
     desc, inp = workloads.make_batch(ctx, cfg, B=B)

@@ -17,12 +17,13 @@ COST_RTOL = 1e-4
 GENERAL_SWEEP = {"C2nd", "C4t1", "C4", "C2ndd", "C1t", "C4h", "C2ndal", "C4t1al", "C4al", "C1tal"}  # workloads on the 2nd-order / time systems' sweeps
 
 
-@pytest.fixture(autouse=True, params=["v2", "v1", "v2rows"])
+@pytest.fixture(autouse=True, params=["v2", "v1", "v2rows", "v2wg"])
 def hip_path(request, monkeypatch):
     """Every test runs on both kernel sets: v2 = alpha-parallel line search + register-resident / matrix-core sweeps (default), v1 = generic
     lane-per-instance kernels.  The 2nd-order / time systems have two v2 sweeps chosen by batch size (one instance per wave on the matrix cores;
     16 lanes per instance with rows in registers beyond two waves per SIMD): "v2rows" forces the second one at test sizes, for the cases that
-    reach it.  (Test plumbing of capi.py: the variables become ilqr_ctx_set_crosscheck before every solve; the library reads no environment.)"""
+    reach it.  The single-integrator systems have two v2 forward passes chosen by batch size (16 lanes per instance on registers for small
+    batches; the bandwidth-built 32-lanes-per-instance workgroup beyond): "v2wg" forces the second one at test sizes.  (Test plumbing of capi.py: the variables become ilqr_ctx_set_crosscheck before every solve; the library reads no environment.)"""
     if request.param == "v2rows":
         cfg = request.node.callspec.params.get("cfg_name") if hasattr(request.node, "callspec") else None
         name = request.node.callspec.params.get("name") if hasattr(request.node, "callspec") else None
@@ -30,6 +31,13 @@ def hip_path(request, monkeypatch):
             pytest.skip("not on the 2nd-order / time systems' sweep")
         monkeypatch.setenv("ILQR_HIP_PATH", "v2")
         monkeypatch.setenv("ILQR_SWEEP", "rows")
+    elif request.param == "v2wg":
+        cfg = request.node.callspec.params.get("cfg_name") if hasattr(request.node, "callspec") else None
+        name = request.node.callspec.params.get("name") if hasattr(request.node, "callspec") else None
+        if not ((cfg is not None and cfg not in GENERAL_SWEEP) or (name and not ("TIME" in name or "2ND" in name))):
+            pytest.skip("not a parametrised case of the single-integrator systems")
+        monkeypatch.setenv("ILQR_HIP_PATH", "v2")
+        monkeypatch.setenv("ILQR_FWD", "wg")
     else:
         monkeypatch.setenv("ILQR_HIP_PATH", request.param)
     return request.param
