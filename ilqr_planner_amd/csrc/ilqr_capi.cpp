@@ -568,7 +568,7 @@ static Bufs half_bufs(const ilqr_problem* p, int half) {
     v.desc = p->ddesc_half[half];
     for (int i = 0; i < 2; i++) { v.X[i] += o; v.U[i] += o; }
     v.U0 += o; v.q0 += o; v.dq0 += o; v.kp_tg += o;
-    v.KD += o * (size_t)p->dims.n_u * kd_rowp(p->dims.n_x);
+    v.KD += o * (size_t)kd_rs(p->bufs.kd_sym, p->dims.n_u, kd_rowp(p->dims.n_x));
     v.cost += o; v.alpha += o; v.cur += o; v.active += o; v.iters += o; v.status += o; v.kpd += o; v.pend += o; v.pred += o;
     v.lsc += o; v.dun += o; v.kpdev += o; v.kpx += o; v.dunA += o;
     if (v.cost_trace) { v.cost_trace += o; v.alpha_trace += o; }
@@ -604,6 +604,10 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
     bool uniform_R = true;
     for (int i = 1; i < p->dims.n_u; i++) uniform_R = uniform_R && (p->desc.R_diag[i] == p->desc.R_diag[0]);
     const bool fused = bwd_si && fwd_wave;  // the sweep applies the previous line search's winner itself (ilqr_kernels_dpp.hip)
+    // uniform control weights: the sweep's closed form for N = M D - I with D a multiple of I, writing the packed symmetric gain record (ilqr_kernels.hpp:
+    // KD_SYM_RS) that the two forward passes of this path and the getters read; any other forward pass reads plain records, so then the general form runs
+    const bool unif_sym = bwd_si && uniform_R && fwd_wave;
+    p->bufs.kd_sym = unif_sym ? 1 : 0;
 
     // ---- one or two independent halves ("lanes" of the launch schedule).  Instances never interact, so the halves of a large batch are
     // two complete solves on two streams; the second one starts one sweep later, so that its latency-bound sweep runs under the other
@@ -695,7 +699,7 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
                 // rows in registers, DPP broadcasts (ilqr_kernels_dpp.hip): 16 lanes per instance while that gives every SIMD at most one wave
                 // (the launch is then bound by one wave's instruction stream, which is shorter with 4 instances per wave), 8 lanes per
                 // instance beyond (half the instructions per instance).  Measured crossover between 4096 and 8192 instances on 1024 SIMDs.
-                if (bwd_si) launch_backward_si_dpp(al, fused, uniform_R, (B + 3) / 4 <= c->n_simd ? 16 : 8, bf, B, st, sw);
+                if (bwd_si) launch_backward_si_dpp(al, fused, unif_sym, (B + 3) / 4 <= c->n_simd ? 16 : 8, bf, B, st, sw);
                 else if (bwd_rows) launch_backward_rows(kind, nd, al, bf, B, st);
                 else if (bwd_mfma) launch_backward_mfma(kind, nd, al, bf, B, st);
                 else launch_solver(kind, nd, KER_BACKWARD, al, bf, B, st, fi);
@@ -813,7 +817,7 @@ static int get_gains(ilqr_problem* p, double* K, double* d) {
     const int T1 = p->T - 1, nu = p->dims.n_u, nx = p->dims.n_x;
     const size_t n = (size_t)p->B * T1 * nu * (K ? nx : 1);
     if (ensure_staging(p, n)) return 1;
-    launch_get_gains(p->bufs.KD, p->bufs.alpha, p->bufs.iters, K ? p->staging : nullptr, K ? nullptr : p->staging, p->B, p->Bp, T1, nu, nx, c->stream);
+    launch_get_gains(p->bufs.KD, p->bufs.kd_sym, p->bufs.alpha, p->bufs.iters, K ? p->staging : nullptr, K ? nullptr : p->staging, p->B, p->Bp, T1, nu, nx, c->stream);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(dst, p->staging, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

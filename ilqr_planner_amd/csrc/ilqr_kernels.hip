@@ -494,17 +494,17 @@ __global__ void k_from_soa_scaled(const double* __restrict__ src, const double* 
 }
 
 // gains in the reference's layout: K[B][T-1][NU][NX], d[B][T-1][NU] scaled by the accepted alpha (ILQRRecursive.cpp:128,144,162)
-__global__ void k_get_gains(const double* __restrict__ kd, const double* __restrict__ alpha, const int* __restrict__ iters,
+__global__ void k_get_gains(const double* __restrict__ kd, int sym, const double* __restrict__ alpha, const int* __restrict__ iters,
                             double* __restrict__ K_out, double* __restrict__ d_out, int B, int Bp, int T1, int nu, int nx) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
     if (b >= B) return;
-    const int rowp = kd_rowp(nx), rs = nu * rowp;
+    const int rowp = kd_rowp(nx), rs = kd_rs(sym, nu, rowp);  // (sym: the packed symmetric record of the uniform-R single-integrator sweep)
     const double* rec = KD_REC(kd, Bp, rs, k, b);
     const double sc = (iters[b] > 0) ? alpha[b] : 1.0;
     for (int i = 0; i < nu; i++) {
         if (K_out)
-            for (int j = 0; j < nx; j++) K_out[(((size_t)b * T1 + k) * nu + i) * nx + j] = rec[i * rowp + j];
-        if (d_out) d_out[((size_t)b * T1 + k) * nu + i] = sc * rec[i * rowp + nx];
+            for (int j = 0; j < nx; j++) K_out[(((size_t)b * T1 + k) * nu + i) * nx + j] = rec[kd_off(sym, rowp, i, j)];
+        if (d_out) d_out[((size_t)b * T1 + k) * nu + i] = sc * rec[kd_off(sym, rowp, i, nx)];
     }
 }
 
@@ -535,13 +535,13 @@ __global__ void k_track(Bufs a, const double* __restrict__ x_meas, int k, int wi
     if (b >= d.B) return;
     const int Bp = d.Bp;
     const int cur = a.cur[b];
-    const int rowp = kd_rowp(nx), rs = nu * rowp;
+    const int sym = a.kd_sym, rowp = kd_rowp(nx), rs = kd_rs(sym, nu, rowp);
     const double* rec = KD_REC(a.KD, Bp, rs, k, b);
     const double sc = (a.iters[b] > 0) ? a.alpha[b] : 1.0;
     for (int i = 0; i < nu; i++) {
         double s = AT(a.U[cur], k * nu + i, b);
-        for (int j = 0; j < nx; j++) s += rec[i * rowp + j] * (x_meas[(size_t)b * nx + j] - AT(a.X[cur], k * nx + j, b));
-        if (with_ff) s += sc * rec[i * rowp + nx];
+        for (int j = 0; j < nx; j++) s += rec[kd_off(sym, rowp, i, j)] * (x_meas[(size_t)b * nx + j] - AT(a.X[cur], k * nx + j, b));
+        if (with_ff) s += sc * rec[kd_off(sym, rowp, i, nx)];
         u_out[(size_t)b * nu + i] = s;
     }
 }
@@ -637,9 +637,9 @@ void launch_from_soa_cur(const double* s0, const double* s1, const int* cur, dou
 void launch_from_soa_scaled(const double* src, const double* alpha, const int* iters, double* dst, int B, int Bp, int rows, hipStream_t st) {
     hipLaunchKernelGGL(k_from_soa_scaled, dim3((B + 255) / 256, rows), dim3(256), 0, st, src, alpha, iters, dst, B, Bp, rows);
 }
-void launch_get_gains(const double* kd, const double* alpha, const int* iters, double* K_out, double* d_out, int B, int Bp, int T1, int nu, int nx,
+void launch_get_gains(const double* kd, int kd_sym, const double* alpha, const int* iters, double* K_out, double* d_out, int B, int Bp, int T1, int nu, int nx,
                        hipStream_t st) {
-    hipLaunchKernelGGL(k_get_gains, dim3((B + 63) / 64, T1), dim3(64), 0, st, kd, alpha, iters, K_out, d_out, B, Bp, T1, nu, nx);
+    hipLaunchKernelGGL(k_get_gains, dim3((B + 63) / 64, T1), dim3(64), 0, st, kd, kd_sym, alpha, iters, K_out, d_out, B, Bp, T1, nu, nx);
 }
 void launch_warm_start(const Bufs& a, double* U0, double* q0, double* dq0, int shift, int B, int T, int nx, int nu, int nd, hipStream_t st) {
     hipLaunchKernelGGL(k_warm_start, dim3((B + 63) / 64, T - 1), dim3(64), 0, st, a, U0, q0, dq0, shift, nx, nu, nd);

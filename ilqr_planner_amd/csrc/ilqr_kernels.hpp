@@ -41,9 +41,20 @@ struct Bufs {
     const double* conb;  // [T-1 or 1][m]
     double* lambda;      // [T-1][m][Bp]
     double* Is;          // [T-1][m][Bp]  penalty * active-set mask at rollout time
+    int kd_sym;          // the records of KD are in the packed symmetric form of the last solve (see KD_SYM_RS), set by the host per solve
 };
 
 constexpr int kd_rowp(int nx) { return (nx + 2) & ~1; }
+// Packed record of the single-integrator sweep with uniform control weights (k_backward_si_dpp<.., UNIF = true>): there K = N / dt = ((R + reg) M - I) / dt
+// is symmetric (M = S^-1 is, and R + reg is a multiple of I), so the record holds the upper triangle of K row by row (28 entries), d (7) and one pad:
+// 36 doubles = 288 bytes instead of 56 = 448.  Gains are 2/3 of what the forward pass reads and 57 % of what the sweep writes.  Entry (i, j), i > j, is
+// read as (j, i): the two differ in the last bits (the rows of the swept matrix are formed by different lanes), which the parity gates see as rounding.
+constexpr int KD_SYM_RS = 36, KD_SYM_D = 28;
+__host__ __device__ constexpr int kd_sym_tri(int i, int j) { return i * 7 - i * (i - 1) / 2 + (j - i); }          // i <= j < 7
+__host__ __device__ constexpr int kd_sym_off(int i, int j) { return j >= 7 ? KD_SYM_D + i : (i <= j ? kd_sym_tri(i, j) : kd_sym_tri(j, i)); }  // j = 7: d_i
+// offset of entry (i, j) (j = n_x: the feed-forward) in a record of either form, and the record length
+__host__ __device__ inline int kd_off(int sym, int rowp, int i, int j) { return sym ? kd_sym_off(i, j) : i * rowp + j; }
+__host__ __device__ inline int kd_rs(int sym, int nu, int rowp) { return sym ? KD_SYM_RS : nu * rowp; }
 #define KD_REC(kd, Bp, RS, k, b) ((kd) + ((size_t)(k) * (size_t)(Bp) + (size_t)(b)) * (size_t)(RS))
 
 struct FwdArgs {
@@ -96,7 +107,7 @@ void launch_to_soa(const double* src, double* dst, int B, int Bp, int rows, hipS
 void launch_from_soa(const double* src, double* dst, int B, int Bp, int rows, hipStream_t st);
 void launch_from_soa_cur(const double* s0, const double* s1, const int* cur, double* dst, int B, int Bp, int rows, hipStream_t st);
 void launch_from_soa_scaled(const double* src, const double* alpha, const int* iters, double* dst, int B, int Bp, int rows, hipStream_t st);
-void launch_get_gains(const double* kd, const double* alpha, const int* iters, double* K_out, double* d_out, int B, int Bp, int T1, int nu, int nx, hipStream_t st);
+void launch_get_gains(const double* kd, int kd_sym, const double* alpha, const int* iters, double* K_out, double* d_out, int B, int Bp, int T1, int nu, int nx, hipStream_t st);
 void launch_warm_start(const Bufs& a, double* U0, double* q0, double* dq0, int shift, int B, int T, int nx, int nu, int nd, hipStream_t st);
 void launch_track(const Bufs& a, const double* x_meas, int k, int with_ff, double* u_out, int B, int nx, int nu, hipStream_t st);
 void launch_fk_batch(const DevDesc* dd, int n, const double* q, double* pos, double* quat, double* jac, hipStream_t st);

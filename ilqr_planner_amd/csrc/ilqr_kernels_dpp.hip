@@ -169,10 +169,12 @@ template <int LPI, int MR, bool FUSED, bool UNIF>
 __global__ __launch_bounds__(64) void k_backward_si_dpp(Bufs a, SweepArgs sw) {
     constexpr int N = 7, IPW = 64 / LPI;
     constexpr int MRR = MR > 0 ? MR : 1;
-    constexpr int ROWP = kd_rowp(N), RS = N * ROWP;
+    constexpr int ROWP = kd_rowp(N), RS = UNIF ? KD_SYM_RS : N * ROWP;  // uniform R: K is symmetric, the record holds its upper triangle (ilqr_kernels.hpp)
     static_assert(ROWP == 8, "a gain row is the lane's eight doubles {K_r0..K_r6, d_r}");
     static_assert(LPI == 8 || LPI == 16, "");
-    __shared__ __attribute__((aligned(16))) double sK[2][IPW * RS + 64];  // two images of the wave's gain records (written at the end of a step, sent out during the next)
+    // two images of the wave's gain records (written at the end of a step, sent out during the next) + one dump slot per lane behind each
+    constexpr int NPQ_ = (IPW * (RS / 2) + 63) / 64, IMG = (IPW * RS > 128 * NPQ_) ? IPW * RS : 128 * NPQ_;
+    __shared__ __attribute__((aligned(16))) double sK[2][IMG + 64];
     const DevDesc& d = *a.desc;
     const int lane = threadIdx.x, g = lane / LPI, l = lane % LPI;
     const int r = l & 7;                 // row of the matrices / component of the vectors this lane owns (7 = padding: all zeros)
@@ -242,6 +244,16 @@ __global__ __launch_bounds__(64) void k_backward_si_dpp(Bufs a, SweepArgs sw) {
     UNR for (int q = 0; q < NPQ; q++) {
         const int c = lane + 64 * q, gi = (c / PCS < IPW) ? c / PCS : 0;
         pst[q] = c < IPW * PCS && ((okm >> (gi * LPI)) & 1ull);
+    }
+    // where this lane's entries go in the image (doubles): uniform R -- the upper triangle of its row and d_r, the rest to the lane's dump slot
+    int wo[N], wod = IMG + lane;
+    UNR for (int j = 0; j < N; j++) wo[j] = IMG + lane;
+    if (UNIF) {
+        if (isV && low) {
+            UNR for (int j = 0; j < N; j++) wo[j] = (j >= v) ? g * RS + kd_sym_tri(v, j) : IMG + lane;
+            wod = g * RS + KD_SYM_D + v;
+        }
+        if (l == 0) { sK[0][g * RS + KD_SYM_RS - 1] = 0; sK[1][g * RS + KD_SYM_RS - 1] = 0; }  // the pad entry of the record
     }
     double* Kout = KD_REC(a.KD, Bp, RS, T - 2, xcd_tile() * IPW);  // (the gains of a big batch pass 4 GiB: 64-bit pointer)
     const ptrdiff_t Kstep = (ptrdiff_t)Bp * RS;
@@ -373,7 +385,11 @@ __global__ __launch_bounds__(64) void k_backward_si_dpp(Bufs a, SweepArgs sw) {
         // doubled the launch (measured: 381 -> 194 us at B = 8192 with these stores removed).  The rows go into a wave-local LDS image of
         // the wave's records as they lie in memory; the image leaves during the NEXT step as 16-byte pieces of whole lines (1 KiB
         // contiguous per instruction), so neither the LDS round trip nor the stores sit on this step's chain.
-        if (isV && low) {
+        if (UNIF) {  // packed symmetric record: row r contributes K_rr .. K_r6 and d_r; everything else (and every lane without a row) writes its dump slot -- no mask
+            double* img = sK[jj & 1];
+            UNR for (int j = 0; j < N; j++) img[wo[j]] = Kr[j];
+            img[wod] = dv;
+        } else if (isV && low) {
             double2* w = reinterpret_cast<double2*>(&sK[jj & 1][g * RS + v * ROWP]);
             w[0] = make_double2(Kr[0], Kr[1]);
             w[1] = make_double2(Kr[2], Kr[3]);

@@ -151,14 +151,23 @@ __global__ __launch_bounds__(FW_IW * 32) void k_forward_wg(Bufs a, FwdArgs f) {
     };
 
     // ---- gain ring
-    const double* pK = a.KD + (size_t)bb * RS + r * ROWP + c0;  // 16-byte aligned
-    const size_t sK_ = (size_t)Bp * RS;
+    // plain record: the lane's two entries are adjacent (one 16-byte load); packed symmetric record (a.kd_sym, ilqr_kernels.hpp): entry (r, c) lies at
+    // (min, max) of the upper triangle, d_r behind it -- two 8-byte loads, the lanes of an instance still cover one contiguous record
+    const int sym = a.kd_sym, rs_ = kd_rs(sym, NU, ROWP);
+    const double* pK = a.KD + (size_t)bb * rs_ + kd_off(sym, ROWP, r, c0);  // plain: 16-byte aligned
+    const double* pK1 = a.KD + (size_t)bb * rs_ + kd_off(sym, ROWP, r, c1);
+    const size_t sK_ = (size_t)Bp * rs_;
     double rk0[S], rk1[S];
-    auto fetch = [&](int slot, int k) {  // unconditional; the pointer stops at the last timestep
-        const double2 v2 = *reinterpret_cast<const double2*>(pK);
-        rk0[slot] = v2.x;
-        rk1[slot] = v2.y;
-        if (k < T - 2) pK += sK_;  // uniform; no load inside the branch
+    auto fetch = [&](int slot, int k) {  // unconditional; the pointers stop at the last timestep
+        if (sym) {  // uniform
+            rk0[slot] = *pK;
+            rk1[slot] = *pK1;
+        } else {
+            const double2 v2 = *reinterpret_cast<const double2*>(pK);
+            rk0[slot] = v2.x;
+            rk1[slot] = v2.y;
+        }
+        if (k < T - 2) { pK += sK_; pK1 += sK_; }  // uniform; no load inside the branch
     };
     block_load(0);
     __builtin_amdgcn_sched_barrier(0);
@@ -321,17 +330,25 @@ __device__ __forceinline__ bool forward_dpp_body(const Bufs& a, const FwdArgs& f
     const int n_kp = d.n_kp;
     int kpi = 0, kp_next = (n_kp > 0) ? d.kp_t[0] : -1;
 
-    const size_t Vstep = (size_t)NX * Bp, Kstep = (size_t)Bp * RS;
+    const size_t Vstep = (size_t)NX * Bp;
     const double* pV = (h ? a.U[cur] : a.X[cur]) + (size_t)r * Bp + bb;      // xbar_r (half 0) | ubar_r (half 1): same stride
-    const double* pK = a.KD + (size_t)bb * RS + r * ROWP + 4 * h;             // this half's 32 bytes of the row
+    const int sym = a.kd_sym, rs_ = kd_rs(sym, NU, ROWP);                     // packed symmetric record (ilqr_kernels.hpp): four 8-byte loads
+    const double* pK = a.KD + (size_t)bb * rs_ + (sym ? 0 : r * ROWP + 4 * h);  // plain: this half's 32 bytes of the row
+    int ko[4];
+    UNR for (int j = 0; j < 4; j++) ko[j] = sym ? kd_sym_off(r, 4 * h + j) : j;
+    const size_t Kstep = (size_t)Bp * rs_;
     double* qV = (h ? a.U[1 - cur] : a.X[1 - cur]) + (size_t)r * Bp + bb;
     const double xT = a.X[cur][((size_t)(T - 1) * NX + r) * Bp + bb];         // terminal xbar
 
     double Kr[PF][4], vr[PF];
     auto fetch = [&](int slot, int kk) {  // unconditional; the pointers stop at the last control step
-        const double2* k2 = reinterpret_cast<const double2*>(pK);
-        const double2 v0 = k2[0], v1 = k2[1];
-        Kr[slot][0] = v0.x; Kr[slot][1] = v0.y; Kr[slot][2] = v1.x; Kr[slot][3] = v1.y;
+        if (sym) {  // uniform
+            UNR for (int j = 0; j < 4; j++) Kr[slot][j] = pK[ko[j]];
+        } else {
+            const double2* k2 = reinterpret_cast<const double2*>(pK);
+            const double2 v0 = k2[0], v1 = k2[1];
+            Kr[slot][0] = v0.x; Kr[slot][1] = v0.y; Kr[slot][2] = v1.x; Kr[slot][3] = v1.y;
+        }
         vr[slot] = *pV;
         const bool more = kk < T - 2;  // uniform: a scalar select, not a branch
         pK += more ? Kstep : 0; pV += more ? Vstep : 0;
