@@ -441,6 +441,9 @@ def main():
                         timing="HIP events on the library's stream, separate pass after the timed region")
             if trials is not None:
                 roof["mean_line_search_trials"] = round(trials, 3)
+            if fused:  # uniform control weights: K = N / dt is symmetric and the sweep writes its upper triangle (36 of the 56 doubles of a gain record)
+                roof["traffic_note"] = ("algorithmic bytes count the full gain record K | d of SURVEY 8(d) (56 doubles per instance-step); the kernels move its packed "
+                                        "symmetric form (36 doubles), so the measured traffic lies BELOW the algorithmic bytes")
             # what share of the solve the rated kernels are: a roofline fraction speaks for its own kernel only
             tot_ms = sum(v["total_ms"] for v in kern.values())
             roof["rated_share_of_solve"] = round(sum(v["total_ms"] for v in rated.values()) / tot_ms, 4) if tot_ms else None

@@ -332,26 +332,28 @@ __device__ __forceinline__ bool forward_dpp_body(const Bufs& a, const FwdArgs& f
 
     const size_t Vstep = (size_t)NX * Bp;
     const double* pV = (h ? a.U[cur] : a.X[cur]) + (size_t)r * Bp + bb;      // xbar_r (half 0) | ubar_r (half 1): same stride
-    const int sym = a.kd_sym, rs_ = kd_rs(sym, NU, ROWP);                     // packed symmetric record (ilqr_kernels.hpp): four 8-byte loads
-    const double* pK = a.KD + (size_t)bb * rs_ + (sym ? 0 : r * ROWP + 4 * h);  // plain: this half's 32 bytes of the row
-    int ko[4];
-    UNR for (int j = 0; j < 4; j++) ko[j] = sym ? kd_sym_off(r, 4 * h + j) : j;
+    // gains: a wave-uniform base that walks the horizon (scalar registers) + the lane's 32-bit byte offsets into the step's records -- no vector address
+    // arithmetic per load.  Plain record: this half's 32 bytes of the row (two 16-byte loads); packed symmetric record (a.kd_sym, ilqr_kernels.hpp): four 8-byte loads
+    const int sym = a.kd_sym, rs_ = kd_rs(sym, NU, ROWP);
+    const double* kb = a.KD;
+    unsigned ko[4];
+    UNR for (int j = 0; j < 4; j++) ko[j] = ((unsigned)bb * rs_ + (sym ? kd_sym_off(r, 4 * h + j) : r * ROWP + 4 * h + j)) * 8u;
     const size_t Kstep = (size_t)Bp * rs_;
     double* qV = (h ? a.U[1 - cur] : a.X[1 - cur]) + (size_t)r * Bp + bb;
     const double xT = a.X[cur][((size_t)(T - 1) * NX + r) * Bp + bb];         // terminal xbar
 
     double Kr[PF][4], vr[PF];
     auto fetch = [&](int slot, int kk) {  // unconditional; the pointers stop at the last control step
+        const char* kbb = reinterpret_cast<const char*>(kb);
         if (sym) {  // uniform
-            UNR for (int j = 0; j < 4; j++) Kr[slot][j] = pK[ko[j]];
+            UNR for (int j = 0; j < 4; j++) Kr[slot][j] = *reinterpret_cast<const double*>(kbb + ko[j]);
         } else {
-            const double2* k2 = reinterpret_cast<const double2*>(pK);
-            const double2 v0 = k2[0], v1 = k2[1];
+            const double2 v0 = *reinterpret_cast<const double2*>(kbb + ko[0]), v1 = *reinterpret_cast<const double2*>(kbb + ko[2]);
             Kr[slot][0] = v0.x; Kr[slot][1] = v0.y; Kr[slot][2] = v1.x; Kr[slot][3] = v1.y;
         }
         vr[slot] = *pV;
         const bool more = kk < T - 2;  // uniform: a scalar select, not a branch
-        pK += more ? Kstep : 0; pV += more ? Vstep : 0;
+        kb += more ? Kstep : 0; pV += more ? Vstep : 0;
     };
     UNR for (int q = 0; q < PF; q++) { fetch(q, q); __builtin_amdgcn_sched_barrier(0); }
 

@@ -39,6 +39,9 @@ def config(name: str):
                     nb_iter=8),
         # C2: "pos-only" = zero orientation precision (POS_ORN_MULTI_SYS.ipynb cell 12)
         "C2": dict(kind=capi.SYS_POS_ORN, nb_deriv=1, T=100, dt=0.1, B=256, seed=1, Qdiag=[[1, 1, 1, 0, 0, 0]] * 2, solver="recursive", nb_iter=20),
+        # the same with joint-dependent control weights: K is not symmetric then, the sweep takes its general form and writes plain gain records
+        "C2r": dict(kind=capi.SYS_POS_ORN, nb_deriv=1, T=60, dt=0.1, B=64, seed=21, Qdiag=[[1, 1, 1, 0, 0, 0]] * 2, solver="recursive", nb_iter=12,
+                    R_diag=[1e-5, 2e-5, 5e-6, 1e-5, 3e-5, 1e-5, 4e-6]),
         # C3: AL-iLQR with the tutorial's single row q_6 <= 2.0 (penalty .25, scaling 1.1, update every 5)
         "C3": dict(kind=capi.SYS_POS_ORN, nb_deriv=1, T=200, dt=0.05, B=4096, seed=2, Qdiag=[P, P], solver="al", nb_iter=20,
                    al=dict(row=5, bound=2.0, penalty=0.25, scaling=1.1, lag=5)),
@@ -109,7 +112,7 @@ def make_batch(ctx: capi.Context, cfg: dict, B: int | None = None, seed: int | N
     if nd == 2:
         smax[dof:2 * dof], smin[dof:2 * dof], w[dof:2 * dof] = 10.0, -10.0, 1
     hyb = bool(cfg.get("hybrid"))
-    desc = capi.make_desc(kind=kind, nb_deriv=nd, horizon=T, dt=cfg["dt"], R_diag=[1e-5] * nu, chain=chain, kp_timesteps=kp_t,
+    desc = capi.make_desc(kind=kind, nb_deriv=nd, horizon=T, dt=cfg["dt"], R_diag=control_weights(cfg, nu), chain=chain, kp_timesteps=kp_t,
                           kp_Q=[np.diag(q) for q in cfg["Qdiag"]], limits=dict(state_max=smax, state_min=smin, limit_weight=w, penalty=1.0),
                           kp_dist=cfg.get("kp_dist"), kp_joint=[1, 0] if hyb else None, kp_Ru=[[1e-3] * nu, [1e-5] * nu] if hyb else None,
                           limit_multiplicity=(1 if cfg.get("limits2") else 2) if hyb else 1,
@@ -212,6 +215,12 @@ def load_batch(ctx: capi.Context, desc, inp, B: int) -> capi.BatchProblem:
     if "A" in inp:
         p.set_constraints(inp["A"], inp["b"], inp["lambda0"])
     return p
+
+
+def control_weights(cfg: dict, nu: int):
+    """R of a workload: 1e-5 I unless the configuration names its own diagonal ("R_diag": per-joint weights; a time control keeps 1e-5)."""
+    r = list(cfg.get("R_diag", []))
+    return [float(r[i]) if i < len(r) else 1e-5 for i in range(nu)]
 
 
 def run_solver(p: capi.BatchProblem, cfg: dict, nb_iter=None, early_stop=False, psi=None):

@@ -129,6 +129,7 @@ def test_tutorial_traces_on_gpu(ctx, name, idx, hip_path):
                                                        ("C1", 1, 10, "inactive"), ("C1j", 96, 8, "inactive"), ("C1j", 48, 8, "active"), ("C1t", 64, 10, "inactive"),
                                                        ("C2h", 96, 12, "inactive"), ("C2h", 48, 12, "urdf"), ("C4h", 48, 12, "inactive"),  # hybrid sequences
                                                        ("C2hl", 48, 12, "urdf"),
+                                                       ("C2r", 64, 12, "inactive"), ("C2r", 32, 12, "urdf"),  # joint-dependent control weights: general sweep form, plain gain records
                                                        ("C2ndal", 32, 10, "inactive"), ("C4t1al", 32, 10, "inactive"), ("C4al", 24, 8, "inactive"), ("C4al", 16, 8, "urdf"),  # AL on the 2nd-order and time systems
                                                        ("C1jal", 32, 8, "inactive"), ("C1tal", 32, 8, "inactive")])  # ... and on the joint-space systems  # ... whose sub-systems have different bounds (second limit set)  # JointSpacePlannerSys (C1 = BASELINE configs[0])
 def test_random_batch_vs_oracle(ctx, cfg_name, B, nb_iter, limits, hip_path):
@@ -174,11 +175,13 @@ def test_random_batch_vs_oracle(ctx, cfg_name, B, nb_iter, limits, hip_path):
             np.testing.assert_allclose(U[i][:, :nuo], r["U"], rtol=0, atol=2e-3)
 
 
-def test_gains_and_fx_outputs(ctx):
-    """K_t, d_t (scaled by the accepted alpha) and f(X) against the oracle on a small batch."""
+@pytest.mark.parametrize("cfg_name", ["C2", "C2r"])
+def test_gains_and_fx_outputs(ctx, cfg_name):
+    """K_t, d_t (scaled by the accepted alpha) and f(X) against the oracle on a small batch.  C2: uniform control weights -- the sweep writes the
+    packed symmetric gain record (K = N / dt is symmetric: 36 doubles per instance-step), the getter unpacks it; C2r: joint-dependent weights, plain records."""
     from ilqr_planner_amd import workloads
 
-    cfg = workloads.config("C2")
+    cfg = workloads.config(cfg_name)
     B, nb_iter = 8, 3
     desc, inp = workloads.make_batch(ctx, cfg, B=B, seed=11)
     p = workloads.load_batch(ctx, desc, inp, B)
