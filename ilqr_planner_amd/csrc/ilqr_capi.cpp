@@ -656,8 +656,9 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
     f.line_search = line_search; f.early_stop = early_stop; f.nb_iter = nb_iter; f.penalty_roll = penalty0; f.n_alpha = n_alpha; f.al = al ? 1 : 0; f.n_kp = p->desc.n_kp;
     f.fused = fused ? 1 : 0;
     f.limits = p->desc.limits_set ? 1 : 0;
-    // small batches (at most FWD_SMALL_WAVES_PER_SIMD waves of 4 instances per SIMD): the rollout is a chain, not a stream -- k_forward_dpp
-    f.small = (fwd_wave && c->xc_fwd != 1 && (c->xc_fwd == 2 || (p->B + 3) / 4 <= c->n_simd / 2)) ? 1 : 0;
+    // small batches (up to three quarters of a wave of 4 instances per SIMD): the rollout is a chain, not a stream -- k_forward_dpp.  Measured crossover
+    // with k_forward_wg on C3 (forward + decision, us): B = 2048 92 / 122, 3072 114 / 124, 4096 139 / 126
+    f.small = (fwd_wave && c->xc_fwd != 1 && (c->xc_fwd == 2 || (p->B + 3) / 4 <= 3 * c->n_simd / 4)) ? 1 : 0;
     for (int k = 0; k < p->desc.n_kp; k++) f.kp_ext |= p->desc.kp_dist[k] | p->desc.kp_has_frame[k] | p->desc.kp_has_Ru[k] | p->desc.kp_joint[k];
     for (int h = 0; h < nh; h++) {
         const Bufs& bf = hv[h].bufs;
