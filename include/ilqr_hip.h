@@ -150,7 +150,8 @@ int ilqr_ctx_set_stream(ilqr_ctx* ctx, void* hip_stream);
 int ilqr_ctx_synchronize(ilqr_ctx* ctx);
 /* Large batches of the systems that use the wave-per-instance MFMA sweep are solved as two halves on two internal streams, joined to the
  * context's stream by events (instances are independent: results do not depend on it).  on = 0 keeps every launch on the context's
- * stream, one kernel at a time -- what a profiler run wants.  Default: on.  (No reference counterpart: the reference has no batch.) */
+ * stream, one kernel at a time -- what a profiler run wants.  Default: on (1).  on = 2 splits every cooperative path (experiments only: measured
+ * slower on the single-integrator systems).  (No reference counterpart: the reference has no batch.) */
 int ilqr_ctx_set_split(ilqr_ctx* ctx, int on);
 /* Cross-check kernel variants for parity tests (no reference counterpart; the library reads no environment variable -- these are context state,
  * in force for every later solve on the context): generic_kernels = 1 runs ILQRRecursive / AL_ILQR on the generic one-lane-per-instance kernel
