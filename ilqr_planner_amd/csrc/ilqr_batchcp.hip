@@ -386,7 +386,7 @@ ILQR_DEV void cpl_states(const DevDesc& d, const CPArgs& c, int b, int kpi, cons
 }
 // e'Qe at the keypoints + limit term of the pre-step states + control cost, all as functions of w (BatchILQRCP.cpp:135,150)
 template <class S, int KWP>
-ILQR_DEV double cpl_cost(const DevDesc& d, const Bufs& a, const CPArgs& c, int b, const double* w, const double* g0, double c00) {
+ILQR_DEV double cpl_cost(const DevDesc& d, const Bufs& a, const CPArgs& c, int b, const double* w, double c00) {
     constexpr int NX = S::NX;
     const int Bp = d.Bp;
     double cost_e = 0, cost_l = 0;
@@ -401,13 +401,18 @@ ILQR_DEV double cpl_cost(const DevDesc& d, const Bufs& a, const CPArgs& c, int b
             UNR for (int r = 0; r < NX; r++) cost_l += ql[r] * Ld[r] * ql[r];
         }
     }
+    // g0 = PSI'R u0 is read HERE, behind the keypoint code (held from the start of the kernel its 16 values were part of what pushed the line-search
+    // kernel over the register file: 132 bytes of scratch in the code-object audit of round 3), and used behind the quadratic form, which covers the
+    // loads' latency.  lin and quad are separate sums: the same bits in either order.
+    double g0v[KWP];
+    UNR for (int q = 0; q < KWP; q++) g0v[q] = AT(c.g0, q, b);
     double lin = 0, quad = 0;
     UNR for (int q = 0; q < KWP; q++) {
         double s = 0;
         UNR for (int r = 0; r < KWP; r++) s += c.H0[q * KWP + r] * w[r];
-        lin += g0[q] * w[q];
         quad += w[q] * s;
     }
+    UNR for (int q = 0; q < KWP; q++) lin += g0v[q] * w[q];
     // the padded diagonal of H0 is 1 (keeps H regular); the padded w entries are 0, so it adds nothing
     return cost_e + ((c00 + 2 * lin) + quad) + cost_l;
 }
@@ -452,7 +457,7 @@ __global__ __launch_bounds__(LPB) void k_cpl_linearize(Bufs a, CPArgs c) {
     if (kpi != 0) return;
     double g0[KWP];
     UNR for (int q = 0; q < KWP; q++) g0[q] = AT(c.g0, q, b);
-    if (c.it == 0) a.cost[b] = cpl_cost<S, KWP>(d, a, c, b, w, g0, c.c00[b]);  // cost0 (BatchILQRCP.cpp:135)
+    if (c.it == 0) a.cost[b] = cpl_cost<S, KWP>(d, a, c, b, w, c.c00[b]);  // cost0 (BatchILQRCP.cpp:135)
     UNR for (int q = 0; q < KWP; q++) {  // PSI'R u = PSI'R u0 + (PSI'R PSI) w   (padded rows of H0: identity x 0)
         double s = g0[q];
         UNR for (int r = 0; r < KWP; r++) s += ((q < c.Kw && r < c.Kw) ? c.H0[q * KWP + r] : 0.0) * w[r];
@@ -478,12 +483,11 @@ __global__ __launch_bounds__(64) void k_cpl_linesearch(Bufs a, CPArgs c) {
     if (!__ballot(ok ? 1 : 0)) return;
     const int b = ok ? bq : 0;
     const int Bp = d.Bp;
-    double w[KWP], dw[KWP], g0[KWP], wn[KWP];
-    UNR for (int q = 0; q < KWP; q++) { w[q] = AT(c.wv, q, b); dw[q] = AT(c.dw, q, b); g0[q] = AT(c.g0, q, b); }
+    double wn[KWP];
     const double cost0 = a.cost[b], c00 = c.c00[b];
     const double alpha = ldexp(1.0, -(l < 11 ? l : 10));
-    UNR for (int q = 0; q < KWP; q++) wn[q] = w[q] + alpha * dw[q];
-    const double cost = cpl_cost<S, KWP>(d, a, c, b, wn, g0, c00);
+    UNR for (int q = 0; q < KWP; q++) wn[q] = AT(c.wv, q, b) + alpha * AT(c.dw, q, b);  // (w, dw are not held: dw is read again for the stop test)
+    const double cost = cpl_cost<S, KWP>(d, a, c, b, wn, c00);
     const bool take = (l < 11) && ((cost < cost0) || (alpha < 1e-3));
     const unsigned long long m = __ballot(take ? 1 : 0);
     const unsigned grp = (unsigned)((m >> (lane & ~(LPI - 1))) & ((1u << LPI) - 1));  // this instance's lanes; lane l = 10 always votes
@@ -502,8 +506,8 @@ __global__ __launch_bounds__(64) void k_cpl_linesearch(Bufs a, CPArgs c) {
         double dun2 = 0;  // sum_k ||PSI_k dw||^2
         UNR for (int q = 0; q < KWP; q++) {
             double s = 0;
-            UNR for (int r = 0; r < KWP; r++) s += c.pp[q * KWP + r] * dw[r];
-            dun2 += dw[q] * s;
+            UNR for (int r = 0; r < KWP; r++) s += c.pp[q * KWP + r] * AT(c.dw, r, b);
+            dun2 += AT(c.dw, q, b) * s;
         }
         if (alpha * sqrt(dun2 > 0 ? dun2 : 0.0) < 1e-3) a.active[b] = 0;  // :167
     }
