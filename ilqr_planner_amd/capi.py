@@ -266,9 +266,10 @@ class Context:
 
     def crosscheck_from_env(self):
         """TEST PLUMBING of this Python wrapper (the library itself reads no environment variable): the parity tests select the cross-check
-        variants per test case through ILQR_HIP_PATH=v1, ILQR_CP_SOLVE=lane, ILQR_CP=general, ILQR_SWEEP=mfma|rows, ILQR_FWD=wg|dpp; every solve of BatchProblem passes them on."""
+        variants per test case through ILQR_HIP_PATH=v1, ILQR_CP_SOLVE=lane, ILQR_CP=general, ILQR_SWEEP=mfma|rows, ILQR_FWD=wg|dpp, ILQR_APPLY=rows|dpp; every solve of BatchProblem passes them on."""
         self.set_crosscheck(os.environ.get("ILQR_HIP_PATH") == "v1", os.environ.get("ILQR_CP_SOLVE") == "lane", os.environ.get("ILQR_CP") == "general",
-                            {"mfma": 1, "rows": 2}.get(os.environ.get("ILQR_SWEEP"), 0) + 4 * {"wg": 1, "dpp": 2}.get(os.environ.get("ILQR_FWD"), 0))
+                            {"mfma": 1, "rows": 2}.get(os.environ.get("ILQR_SWEEP"), 0) + 4 * {"wg": 1, "dpp": 2}.get(os.environ.get("ILQR_FWD"), 0)
+                            + 16 * {"rows": 1, "dpp": 2}.get(os.environ.get("ILQR_APPLY"), 0))
 
     def set_split(self, on: bool):
         """Two-stream solve of large batches on / off (ilqr_ctx_set_split); off = one kernel at a time, for profiler runs."""

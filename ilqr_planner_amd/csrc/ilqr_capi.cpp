@@ -38,6 +38,7 @@ struct ilqr_ctx {
     int n_simd = 1024;  // SIMDs of the device (4 per CU)
     bool xc_generic = false, xc_cp_lane = false, xc_cp_general = false;  // cross-check kernel variants (ilqr_ctx_set_crosscheck)
     int xc_sweep = 0;  // sweep of the 2nd-order / time systems: 0 = by batch size, 1 = matrix-core sweep, 2 = row sweep
+    int xc_apply = 0;  // re-roll of the winner on the time systems: 0 = by batch size, 1 = k_apply_rows_tm, 2 = k_apply_dpp_tm
     int xc_fwd = 0;    // forward pass of the single-integrator systems: 0 = by batch size, 1 = k_forward_wg (bandwidth), 2 = k_forward_dpp (latency)
     hipStream_t half_stream[2] = {nullptr, nullptr};
     hipEvent_t ev_begin = nullptr, ev_half_done[2] = {nullptr, nullptr}, ev_stagger = nullptr;
@@ -167,6 +168,7 @@ extern "C" int ilqr_ctx_set_crosscheck(ilqr_ctx* c, int generic_kernels, int cp_
     if (!c) return 1;
     c->xc_sweep = ((mfma_sweep & 3) == 1 || (mfma_sweep & 3) == 2) ? (mfma_sweep & 3) : 0;
     c->xc_fwd = (((mfma_sweep >> 2) & 3) == 1 || ((mfma_sweep >> 2) & 3) == 2) ? ((mfma_sweep >> 2) & 3) : 0;
+    c->xc_apply = (mfma_sweep >> 4) & 3;
     c->xc_generic = generic_kernels != 0;
     c->xc_cp_lane = cp_lane_solve != 0;
     c->xc_cp_general = cp_general != 0;
@@ -656,6 +658,9 @@ static int solve_riccati(ilqr_problem* p, bool al, int nb_iter, int lag, double 
     f.line_search = line_search; f.early_stop = early_stop; f.nb_iter = nb_iter; f.penalty_roll = penalty0; f.n_alpha = n_alpha; f.al = al ? 1 : 0; f.n_kp = p->desc.n_kp;
     f.fused = fused ? 1 : 0;
     f.limits = p->desc.limits_set ? 1 : 0;
+    // time systems, re-roll of the winner: 16 lanes per instance on registers up to a quarter wave of 4 instances per SIMD (B = 256: 64 against 92 us), the
+    // 8-lanes-per-instance kernel beyond (its waves cover 64 contiguous bytes of every [row][b] line, the other's 32: B = 2048 117 against 126 us, 4096 190 / 240)
+    f.apply_dpp = (c->xc_apply == 2 || (c->xc_apply == 0 && (p->B + 3) / 4 <= c->n_simd / 4)) ? 1 : 0;
     // small batches (up to three quarters of a wave of 4 instances per SIMD): the rollout is a chain, not a stream -- k_forward_dpp.  Measured crossover
     // with k_forward_wg on C3 (forward + decision, us): B = 2048 92 / 122, 3072 114 / 124, 4096 139 / 126
     f.small = (fwd_wave && c->xc_fwd != 1 && (c->xc_fwd == 2 || (p->B + 3) / 4 <= 3 * c->n_simd / 4)) ? 1 : 0;

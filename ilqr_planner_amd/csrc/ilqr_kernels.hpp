@@ -64,6 +64,7 @@ struct FwdArgs {
     int n_alpha;  // number of step sizes 1, 1/2, ... the line search may try (11 for alpha_floor = 1e-3)
     double penalty_roll, penalty_update;
     int kp_ext;   // some keypoint has a dead zone, an object frame or its own control penalty (selects the full keypoint code)
+    int apply_dpp;  // time systems: the re-roll of the winner by k_apply_dpp_tm (16 lanes per instance on registers) instead of k_apply_rows_tm
     int limits;   // the descriptor's limits_set (host copy: selects kernel instantiations)
     int small;    // batch of at most one wave per SIMD: the latency-built forward pass (k_forward_dpp) instead of the bandwidth-built one
     int fused;    // the acceptance of the line search is applied by the next sweep (k_backward_si_dpp<.., true>): until then the accepted

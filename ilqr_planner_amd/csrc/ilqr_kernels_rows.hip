@@ -416,6 +416,171 @@ __global__ __launch_bounds__(64) void k_apply_rows_tm(Bufs a, FwdArgs f) {
     }
 }
 
+
+// The same re-roll with 16 lanes per instance on registers, for SMALL batches (round 3; the design of k_forward_dpp, ilqr_kernels_wave.hip).  k_apply_rows_tm above is a
+// chain of ~0.46 us per step at any batch size: 31 LDS reads per lane and step (gain row and the gathered dx), three LDS exchanges.  Here the chain is 0.3 us per step
+// (B = 256: 64 against 92 us per launch); at large batches the older kernel wins, because its waves hold 8 adjacent instances -- 64 contiguous bytes of every
+// [row][b] line of xbar, ubar, x, u against 32 here (B = 2048: 117 against 126 us, B = 4096: 190 against 240): chosen up to 1024 instances.  Here
+//   lane c < n_x holds state c (q_0..q_6 | dq_0..dq_6 | t) -- its deviation from xbar is the `row_newbcast:c` operand of the FMAs;
+//   lane (h, r), h = half of the 16-lane row, holds entries 8h .. 8h+7 of row r of the gain record and forms its part of du_r = alpha d_r + sum_c K_rc dx_c;
+//   the halves meet by one row_ror:8 move, the time control's step s = u_7 comes out of lane 15, dq_i and u_i reach the lanes that integrate q_i and dq_i by
+//   row_shl:7 / row_shl:1 moves.  No LDS, nothing couples the waves; instances with nothing pending keep re-reading their first record (cache hits).
+#define AD_LO " row_mask:0xf bank_mask:0x3"
+#define AD_HI " row_mask:0xf bank_mask:0xc"
+template <int CTRL>
+__device__ __forceinline__ double ad_dpp(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// this half's part of du_r: half 0 sum_{c<8} K[c] dx_c; half 1 the NHI - 1 remaining columns (broadcast lanes 8 ..) and al * K[NHI-1] (the feed-forward);
+// three accumulators in rotation (a DPP instruction reads its accumulator early: no register is touched again within two instructions)
+template <int NHI>
+__device__ __forceinline__ double ad_half_dot(const double (&K)[8], double x, double al) {
+    static_assert(NHI == 8 || NHI == 1, "n_x = 15 or 8");
+    double s0, s1, s2;
+#define L_(A, J) "v_fmac_f64_dpp %[" A "], %[x], %[k" #J "] row_newbcast:" #J AD_LO "\n\t"
+#define H_(A, J, C) "v_fmac_f64_dpp %[" A "], %[x], %[k" #J "] row_newbcast:" #C AD_HI "\n\t"
+#define F_(A, J) "v_fmac_f64_dpp %[" A "], %[al], %[k" #J "] row_newbcast:0" AD_HI "\n\t"
+#define OPS_ : [s0] "=&v"(s0), [s1] "=&v"(s1), [s2] "=&v"(s2)                                                                              \
+             : [x] "v"(x), [al] "v"(al), [k0] "v"(K[0]), [k1] "v"(K[1]), [k2] "v"(K[2]), [k3] "v"(K[3]), [k4] "v"(K[4]), [k5] "v"(K[5]), [k6] "v"(K[6]), [k7] "v"(K[7])
+#define ZERO_ "v_mov_b64 %[s0], 0\n\tv_mov_b64 %[s1], 0\n\tv_mov_b64 %[s2], 0\n\ts_nop 1\n\t"
+#define LO8_ L_("s0", 0) L_("s1", 1) L_("s2", 2) L_("s0", 3) L_("s1", 4) L_("s2", 5) L_("s0", 6) L_("s1", 7)
+    if (NHI == 8)
+        asm volatile(ZERO_ LO8_ H_("s2", 0, 8) H_("s0", 1, 9) H_("s1", 2, 10) H_("s2", 3, 11) H_("s0", 4, 12) H_("s1", 5, 13) H_("s2", 6, 14) F_("s0", 7) "s_nop 0" OPS_);
+    else
+        asm volatile(ZERO_ LO8_ F_("s2", 0) "s_nop 0" OPS_);
+#undef L_
+#undef H_
+#undef F_
+#undef OPS_
+#undef ZERO_
+#undef LO8_
+    return (s0 + s1) + s2;
+}
+
+template <class S>
+__global__ __launch_bounds__(64) void k_apply_dpp_tm(Bufs a, FwdArgs f) {
+    static_assert(S::TM == 1 && S::NU == 8, "time systems: seven joint controls and the time control");
+    constexpr int NX = S::NX, NU = S::NU, ND = S::ND;
+    constexpr int ROWP = kd_rowp(NX), RS = NU * ROWP, PF = 4, IPW = 4;
+    constexpr int NHI = ROWP - 8 >= 8 ? 8 : 1;       // entries of a row in the second half: 7 gains + d (n_x = 15) or d alone (n_x = 8)
+    static_assert((NX == 15 && ROWP == 16) || (NX == 8 && ROWP == 10), "row halves");
+    // Gain records: the four records of the wave's instances are 4 RS doubles in one run.  Loaded by the lanes that use them -- lane (h, r) its half row -- every load
+    // instruction touches 64 different 64-byte segments and the address unit sets the pace (measured: 262 us per launch at B = 4096 against 186 for k_apply_rows_tm).
+    // So, as there, instruction q loads record q with lane p on its piece p (bytes 16 p ..: one contiguous run), the ring keeps the pieces, and the half rows are picked
+    // out of a double-buffered LDS image of the step, dropped there a step ahead (LDS operations of a wave execute in order: no barrier).  Rows 16 bytes apart
+    // from a multiple of 128 in the image (bank spread).  Records of instances with nothing pending stay on their first timestep: cache hits.
+    constexpr int KS = ROWP + 2, IS = NU * KS, PCS = RS / 2;   // row / record stride of the image (doubles), pieces of a record
+    static_assert(PCS <= 64, "one piece per lane");
+    __shared__ __attribute__((aligned(16))) double sKi[2][IPW * IS];
+    const DevDesc& d = *a.desc;
+    const int lane = threadIdx.x, g = lane >> 4, l = lane & 15, h = l >> 3, r = l & 7;
+    const int b = xcd_tile() * IPW + g;
+    const int Bp = d.Bp, T = d.T, B = d.B;
+    const bool inst_ok = (b < B) && (a.pend[b < B ? b : 0] > 0);
+    if (__ballot(inst_ok ? 1 : 0) == 0ull) return;  // wave-uniform
+    const int bb = (b < B) ? b : 0;
+    const bool isS = l < NX;                          // state lane
+    const int c = isS ? l : 0;
+    const bool isQ = l < DOF, isD = ND == 2 && l >= DOF && l < 2 * DOF, isTm = l == NX - 1;
+    const double alpha = ldexp(1.0, -((inst_ok ? a.pend[bb] : 1) - 1));
+    const int cur = a.cur[bb];
+    const size_t sX_ = (size_t)NX * Bp, sU_ = (size_t)NU * Bp, sK2_ = (size_t)Bp * RS / 2;
+    const double* pX = a.X[cur] + (size_t)c * Bp + bb;
+    const double* pU = a.U[cur] + (size_t)r * Bp + bb;
+    double* oX = a.X[1 - cur] + (size_t)c * Bp + bb;
+    double* oU = a.U[1 - cur] + (size_t)r * Bp + bb;
+
+    const int b0 = b - g;
+    const bool pk = lane < PCS;                       // this lane carries a piece of each record
+    const int prow = pk ? (2 * lane) / ROWP : 0, pcol = pk ? (2 * lane) % ROWP : 0;
+    const int wofs = prow * KS + pcol;                // where the piece goes in a record's image
+    // this half's entries of row r in the image: 16-byte pieces j = 0 .. 3 at 2 j doubles, as far as the row goes (a piece beyond it re-reads piece 0)
+    const int rofs = g * IS + r * KS + 8 * h;
+    int jo[4];
+    UNR for (int j = 0; j < 4; j++) jo[j] = (8 * h + 2 * j < ROWP) ? 2 * j : 0;
+    const double2* const K0 = reinterpret_cast<const double2*>(a.KD + (size_t)b0 * RS) + (pk ? lane : 0);
+    const double2* Kk = K0;                           // records of the step being fetched
+    bool okq[IPW];
+    UNR for (int q = 0; q < IPW; q++) okq[q] = (b0 + q < B) && (a.pend[b0 + q < B ? b0 + q : 0] > 0);  // wave-uniform
+
+    double rk0[PF][IPW], rk1[PF][IPW], xr[PF], ur[PF];  // (two scalar arrays: an array of double2 is not split into registers)
+    auto fetch = [&](int slot, int kk) {  // unconditional; the pointers stop at the last control step, and do not move for an instance with nothing pending
+        UNR for (int q = 0; q < IPW; q++) {
+            const double2 v2 = (okq[q] ? Kk : K0)[(size_t)q * PCS];
+            rk0[slot][q] = v2.x;
+            rk1[slot][q] = v2.y;
+        }
+        xr[slot] = *pX;
+        ur[slot] = *pU;
+        if (kk < T - 2) Kk += sK2_;  // uniform
+        const size_t adv = (kk < T - 2 && inst_ok) ? 1 : 0;
+        pX += adv * sX_; pU += adv * sU_;
+    };
+    auto stage = [&](int slot, int buf) {  // pieces of ring slot -> image buf
+        if (pk) { UNR for (int q = 0; q < IPW; q++) *reinterpret_cast<double2*>(&sKi[buf][q * IS + wofs]) = make_double2(rk0[slot][q], rk1[slot][q]); }
+    };
+    UNR for (int q = 0; q < PF; q++) { fetch(q, q); __builtin_amdgcn_sched_barrier(0); }
+    stage(0, 0);
+    LDS_ORDER();
+
+    // the lane's state: q_c from q0, dq from dq0, the time from 0 (as k_apply_rows_tm)
+    double xv = 0.0;
+    if (isQ) xv = AT(a.q0, c, bb);
+    if (isD) xv = AT(a.dq0, c - DOF, bb);
+
+    const int nsteps = T - 1;
+    static_assert(PF % 2 == 0, "image parity = slot parity");
+    for (int k0 = 0; k0 < nsteps; k0 += PF) {
+        UNR for (int jj = 0; jj < PF; jj++) {
+            const int k = k0 + jj;
+            double Kr[8];
+            UNR for (int j = 0; j < 4; j++) {
+                const double2 v2 = *reinterpret_cast<const double2*>(&sKi[jj & 1][rofs + jo[j]]);  // this lane's half row of step k
+                Kr[2 * j] = v2.x; Kr[2 * j + 1] = v2.y;
+            }
+            const double xb = xr[jj], ub = ur[jj];
+            LDS_ORDER();
+            stage((jj + 1) % PF, (jj + 1) & 1);                     // step k + 1 into the other image
+            LDS_ORDER();
+            __builtin_amdgcn_sched_barrier(0);                      // the slot is free: only now its next load
+            fetch(jj, k + PF);
+            if (k >= nsteps) continue;  // uniform; dummy step of the last group
+            const double dxv = isS ? xv - xb : 0.0;
+            const double part = ad_half_dot<NHI>(Kr, dxv, alpha);
+            const double du = part + ad_dpp<0x128>(part);   // row_ror:8: the other half's part; the same two numbers in both halves
+            const double u = ub + du;
+            const double dts = ad_dpp<0x15F>(u);            // row_newbcast:15: the time control
+            const double dt = dts * dts;
+            if (inst_ok) {
+                if (isS) *oX = xv;
+                if (h == 0) *oU = u;
+            }
+            oX += sX_; oU += sU_;
+            // ---- dynamics (SimulationInterface.cpp:19-31 with dt = u_last^2, PosOrnTimePlannerSys.cpp:149-184): k_apply_rows_tm's expressions per coordinate
+            if (ND == 2) {
+                const double vv = ad_dpp<0x107>(xv);        // row_shl:7: dq_i to the lane of q_i
+                const double un = ad_dpp<0x101>(u);         // row_shl:1: u_i (lane 8 + i) to the lane of dq_i (lane 7 + i)
+                if (isQ) xv = xv + (dt * vv + dt * dt / 2 * u);
+                else if (isD) xv = xv + dt * un;
+                else if (isTm) xv = xv + dt;
+            } else {
+                if (isQ) xv = xv + (dt * u + dt * dt / 2 * 0.0);
+                else if (isTm) xv = xv + dt;
+            }
+        }
+    }
+    if (inst_ok && isS) *oX = xv;  // x_{T-1}
+    if (inst_ok && l == 0) {       // the early stop was decided by k_select_x
+        a.cur[bb] = 1 - cur;
+        a.pend[bb] = 0;
+    }
+}
+#undef AD_LO
+#undef AD_HI
+
 template <class S>
 static void launch_lin_sys(const Bufs& a, int B, int T, hipStream_t st, const FwdArgs& f, int which) {
     if (which == KER_FWD_SPEC) {
@@ -437,6 +602,13 @@ void launch_forward_lin(int nd, int which, const Bufs& a, int B, int T, hipStrea
 }
 
 void launch_apply_rows_tm(int kind, int nd, const Bufs& a, int B, hipStream_t st, const FwdArgs& f) {
+    if (f.apply_dpp) {  // 16 lanes per instance on registers
+        const dim3 g4(grid_x8((B + 3) / 4)), blk(64);
+        if (kind == 3) hipLaunchKernelGGL((k_apply_dpp_tm<Sys<3, 1>>), g4, blk, 0, st, a, f);
+        else if (nd == 1) hipLaunchKernelGGL((k_apply_dpp_tm<Sys<1, 1>>), g4, blk, 0, st, a, f);
+        else hipLaunchKernelGGL((k_apply_dpp_tm<Sys<1, 2>>), g4, blk, 0, st, a, f);
+        return;
+    }
     const dim3 grid(grid_x8((B + 7) / 8)), block(64);
     if (kind == 3) hipLaunchKernelGGL((k_apply_rows_tm<Sys<3, 1>>), grid, block, 0, st, a, f);
     else if (nd == 1) hipLaunchKernelGGL((k_apply_rows_tm<Sys<1, 1>>), grid, block, 0, st, a, f);

@@ -160,7 +160,8 @@ int ilqr_ctx_set_split(ilqr_ctx* ctx, int on);
  * the 2nd-order / time systems: 0 = by batch size (one instance per wave on the f64 matrix cores up to two waves per SIMD, 16 lanes per instance
  * with rows in registers beyond), 1 = always the former, 2 = always the latter (the two agree to rounding, not bit for bit); its bits 2-3 select
  * the forward pass of the single-integrator systems the same way (0 = by batch size, 4 = the bandwidth-built k_forward_wg, 8 = the
- * latency-built k_forward_dpp).  All 0 = the product path. */
+ * latency-built k_forward_dpp); bits 4-5 the re-roll of the line-search winner on the time systems (0 = by batch size, 16 = k_apply_rows_tm,
+ * 32 = k_apply_dpp_tm).  All 0 = the product path. */
 int ilqr_ctx_set_crosscheck(ilqr_ctx* ctx, int generic_kernels, int cp_lane_solve, int cp_general, int mfma_sweep);
 const char* ilqr_version(void);
 

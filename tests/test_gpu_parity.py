@@ -31,6 +31,7 @@ def hip_path(request, monkeypatch):
             pytest.skip("not on the 2nd-order / time systems' sweep")
         monkeypatch.setenv("ILQR_HIP_PATH", "v2")
         monkeypatch.setenv("ILQR_SWEEP", "rows")
+        monkeypatch.setenv("ILQR_APPLY", "rows")  # ... and the large-batch re-roll of the line-search winner (8 lanes per instance through LDS; small batches: k_apply_dpp_tm)
     elif request.param == "v2wg":
         cfg = request.node.callspec.params.get("cfg_name") if hasattr(request.node, "callspec") else None
         name = request.node.callspec.params.get("name") if hasattr(request.node, "callspec") else None
