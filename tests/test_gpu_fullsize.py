@@ -60,6 +60,7 @@ def test_full_size_properties(ctx, cfg_name, B, nb_iter, solver, monkeypatch):
 
     if cfg_name == "C4":  # the sweep of the time systems is chosen by batch size (two kernels that agree to rounding): the bit-for-bit
         monkeypatch.setenv("ILQR_SWEEP", "rows")  # comparison of the big batch with its cut-out is made on the one the big batch takes
+        monkeypatch.setenv("ILQR_APPLY", "rows")  # (likewise the re-roll of the line-search winner: k_apply_rows_tm at this size, k_apply_dpp_tm for small batches)
     if cfg_name == "C3":  # likewise the forward pass of the single-integrator systems (k_forward_wg at this size, k_forward_dpp for small batches)
         monkeypatch.setenv("ILQR_FWD", "wg")
 
@@ -156,6 +157,29 @@ def test_forward_passes_agree(ctx, cfg_name, solver, B, monkeypatch):
     np.testing.assert_allclose(b["cost"], a["cost"], rtol=1e-12, atol=0)
     np.testing.assert_allclose(b["U"], a["U"], rtol=0, atol=1e-11)
     np.testing.assert_allclose(b["X"], a["X"], rtol=0, atol=1e-11)
+
+
+@pytest.mark.parametrize("cfg_name,B", [("C4", 256), ("C4t1", 100), ("C1t", 64)])
+def test_rerolls_of_the_winner_agree(ctx, cfg_name, B, monkeypatch):
+    """Time systems: the winner of the step-size-parallel line search is rolled out again where the speculated step size lost -- by k_apply_dpp_tm (16 lanes
+    per instance on registers) for small batches, by k_apply_rows_tm (8 lanes per instance through LDS) for large ones.  Different summation order: after
+    two iterations from the same start the trajectories agree to rounding; each runs under the per-instance proof in test_gpu_parity.py (v2 / v2rows)."""
+    from ilqr_planner_amd import workloads
+
+    cfg = dict(workloads.config(cfg_name), T=50)
+    desc, inp = workloads.make_batch(ctx, cfg, B=B)
+    res = {}
+    for ap in ("rows", "dpp"):
+        monkeypatch.setenv("ILQR_APPLY", ap)
+        res[ap] = _solve(ctx, cfg, desc, inp, B, 2, "recursive")
+    a, b = res["rows"], res["dpp"]
+    np.testing.assert_array_equal(a["alpha"], b["alpha"])
+    fin = np.isfinite(a["cost"])
+    assert fin.mean() > 0.5 and np.array_equal(fin, np.isfinite(b["cost"]))
+    # (two expanding iterations of a system whose step length is the square of a control: rounding differences of 1e-16 arrive as 1e-10)
+    np.testing.assert_allclose(b["cost"][fin], a["cost"][fin], rtol=1e-8, atol=0)
+    np.testing.assert_allclose(b["U"][fin], a["U"][fin], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(b["X"][fin], a["X"][fin], rtol=0, atol=1e-8)
 
 
 @pytest.mark.parametrize("cfg_name,solver", [("C3", "al"), ("C2", "recursive")])
