@@ -1688,6 +1688,7 @@ BatchResult BatchILQR::solveBatch(const BatchInputs& in, int nb_iter, bool early
     return batch_gauss_newton(*s, nullptr, custom_Q ? &Q : nullptr, in, nb_iter, early_stop);
 }
 Vec BatchILQR::solve(int nb_iter, const Vec& u0, bool early_stop, CallBackMessage* cb) {  // BatchILQR.cpp:110-173
+    if (!s->builtin()) return solve_batch_over_virtuals(*s, nullptr, custom_Q ? Q : s->getQMatrix(true), nb_iter, u0, early_stop, cb);  // user-defined System
     BatchInputs in;
     in.B = 1;
     in.U0 = u0;
@@ -1699,6 +1700,7 @@ Vec BatchILQR::solve(int nb_iter, const Vec& u0, bool early_stop, CallBackMessag
 }
 
 Vec BatchILQRCP::solve(int nb_iter, const Vec& u0, bool early_stop, CallBackMessage* cb) {  // BatchILQRCP.cpp:109-175
+    if (!s->builtin()) return solve_batch_over_virtuals(*s, &PSI, custom_Q ? Q : s->getQMatrix(true), nb_iter, u0, early_stop, cb);  // user-defined System
     BatchInputs in;
     in.B = 1;
     in.U0 = u0;

@@ -481,6 +481,9 @@ std::tuple<std::vector<Vec>, std::vector<Vec>, std::vector<Vec>> solve_al_over_v
                                                                                         const std::vector<Vec>& U0, int nb_iter, int lag_update_step, double penalty,
                                                                                         double scaling_factor, bool line_search, bool early_stop, CallBackMessage* cb);
 
+// BatchILQR (psi = nullptr) / BatchILQRCP over the same interface: one Gauss-Newton step on the whole control sequence per iteration
+Vec solve_batch_over_virtuals(sys::System& s, const Mat* psi, const Mat& Q, int nb_iter, const Vec& u0, bool early_stop, CallBackMessage* cb);
+
 class ILQRRecursive {  // ILQRRecursive.h:21-42
 public:
     explicit ILQRRecursive(const std::shared_ptr<sys::System>& s) : s(s) {}

@@ -1,4 +1,4 @@
-// ilqr_host_loop.cpp -- ILQRRecursive and AL_ILQR over the virtual System interface, for USER-DEFINED System / Keypoint / SimulationInterface
+// ilqr_host_loop.cpp -- ILQRRecursive, AL_ILQR, BatchILQR and BatchILQRCP over the virtual System interface, for USER-DEFINED System / Keypoint / SimulationInterface
 // subclasses only.
 //
 // SURVEY.md section 8(b), last bullet: the reference's solver is written against the virtuals of sys::System (forwardPass, cost, cost_x,
@@ -275,7 +275,119 @@ std::tuple<std::vector<Vec>, std::vector<Vec>, std::vector<Vec>, std::vector<Mat
     if (it_done == 0) { Ks.clear(); dso.clear(); }
     return std::make_tuple(X, fX, U, Ks, dso, cost0);
 }
+// ---- BatchILQR / BatchILQRCP over the virtuals (BatchILQRCP.cpp:109-175, BatchILQR.cpp:111-173; psi == nullptr: the identity basis).
+// One Gauss-Newton step on the whole control sequence per iteration: fpBatch (rollout with A, B, J, L per step), the sensitivities of the keypoint
+// states assembled exactly as buildSuJL does (:61-97 -- including its order of statements: the block of a keypoint step is taken BEFORE that step's
+// [A M, B] update, which is why the reference's W = Su PSI is the true sensitivity shifted by one control), the normal equations
+// solved with inverse(), backtracking on the true cost until it improves or alpha < 1e-3.
+Vec batch_over_virtuals(sys::System& s, const Mat* psi, const Mat& Q, int nb_iter, const Vec& u0, bool early_stop, CallBackMessage* cb) {
+    const int n = s.getNbStateVar(), m = s.getNbCtrlVar(), T = s.getHorizon(), nf = s.getNbTargetVar(), N = m * (T - 1);
+    const std::vector<int> kp = s.getKpIndexes();
+    const int nk = (int)kp.size();
+    if ((int)u0.size() != N) throw std::runtime_error("[BatchILQR] u0 must have (horizon - 1) * nb_ctrl_var entries");
+    if (psi && psi->rows != N) throw std::runtime_error("[BatchILQRCP] psi must have (horizon - 1) * nb_ctrl_var rows");
+    const Mat Rt = s.getRt();
+    auto R_of = [&](int row) { return Rt(row % m, row % m); };  // R = diag(R_t) repeated along the horizon
+    auto is_kp = [&](int i) { for (int t : kp) if (t == i) return true; return false; };
+    auto pick = [&](const Vec& v, int sz) {  // truncateStates: the blocks of the keypoint steps, in keypoint order
+        Vec o((size_t)nk * sz, 0.0);
+        for (int t = 0; t < nk; t++) std::copy(v.begin() + (size_t)kp[t] * sz, v.begin() + (size_t)(kp[t] + 1) * sz, o.begin() + (size_t)t * sz);
+        return o;
+    };
+    using Steps = std::vector<std::tuple<Mat, Mat, Mat, Mat>>;
+    auto limits_of = [&](const Steps& st) {  // buildL: block-diagonal of the keypoint steps' L, in keypoint order
+        Mat L(nk * n, nk * n);
+        for (int t = 0; t < nk; t++) {
+            const Mat& Lt = std::get<3>(st.at(kp[t]));
+            for (int a = 0; a < n; a++) for (int b = 0; b < n; b++) L(t * n + a, t * n + b) = Lt(a, b);
+        }
+        return L;
+    };
+    auto quad = [&](const Vec& v, const Mat& M) { const Vec w = mulv(M, v); double c = 0; for (size_t i = 0; i < v.size(); i++) c += v[i] * w[i]; return c; };
+    auto total = [&](const Vec& e, const Vec& u, const Vec& ql, const Mat& L) {
+        double cu = 0;
+        for (int i = 0; i < N; i++) cu += u[i] * R_of(i) * u[i];
+        return quad(e, Q) + cu + quad(ql, L);
+    };
+
+    s.reset();
+    Vec u = u0;
+    for (int it = 0; it < nb_iter; it++) {
+        auto fp = s.fpBatch(u);
+        const Steps& st = std::get<2>(fp);
+        if ((int)st.size() != T) throw std::runtime_error("[BatchILQR] fpBatch returned the wrong number of steps");
+        const int jr = std::get<2>(st.at(0)).rows, jc = std::get<2>(st.at(0)).cols;
+        Mat Su(nk * n, N), J(nk * jr, nk * jc), L(nk * n, nk * n);
+        {   // buildSuJL, statement for statement
+            Mat M = std::get<1>(st.at(0));
+            int t = 0;
+            for (int i = 0; i < T; i++) {
+                const Mat& At = std::get<0>(st.at(i));
+                const Mat& Bt = std::get<1>(st.at(i));
+                if (is_kp(i)) {
+                    const Mat& Lt = std::get<3>(st.at(i));
+                    for (int a = 0; a < n; a++) for (int b = 0; b < n; b++) L(t * n + a, t * n + b) = Lt(a, b);
+                    if (i > 0)
+                        for (int a = 0; a < M.rows; a++) for (int b = 0; b < M.cols; b++) Su(t * n + a, b) = M(a, b);
+                    const Mat& Jt = std::get<2>(st.at(i));
+                    for (int a = 0; a < jr; a++) for (int b = 0; b < jc; b++) J(t * jr + a, t * jc + b) = Jt(a, b);
+                    t++;
+                }
+                if (i > 0) {
+                    const Mat AM = mul(At, M);
+                    Mat Mn(M.rows, M.cols + Bt.cols);
+                    for (int a = 0; a < M.rows; a++) {
+                        for (int b = 0; b < M.cols; b++) Mn(a, b) = AM(a, b);
+                        for (int b = 0; b < Bt.cols; b++) Mn(a, M.cols + b) = Bt(a, b);
+                    }
+                    M = Mn;
+                }
+            }
+        }
+        const Vec e = s.diffBatch(pick(std::get<0>(fp), nf));
+        const Vec ql = pick(std::get<1>(fp), n);
+        const Mat W = psi ? mul(Su, *psi) : Su;                               // Su PSI
+        const Mat C = add(tmul(J, mul(Q, J)), L);                             // J'QJ + L
+        Mat A = tmul(W, mul(C, W));                                           // + PSI'R PSI
+        const int K = A.rows;
+        for (int a = 0; a < K; a++)
+            for (int b = 0; b < K; b++) {
+                if (psi) { double r = 0; for (int i = 0; i < N; i++) r += (*psi)(i, a) * R_of(i) * (*psi)(i, b); A(a, b) += r; }
+                else if (a == b) A(a, b) += R_of(a);
+            }
+        Vec rhs = tmulv(W, addv(tmulv(J, mulv(Q, e)), mulv(L, ql)));         // PSI'Su'(J'Q e + L ql) - PSI'R u
+        for (int a = 0; a < K; a++) {
+            if (psi) { double r = 0; for (int i = 0; i < N; i++) r += (*psi)(i, a) * R_of(i) * u[i]; rhs[a] -= r; }
+            else rhs[a] -= R_of(a) * u[a];
+        }
+        const Vec dw = mulv(inverse(A), rhs);
+        const Vec du = psi ? mulv(*psi, dw) : dw;
+        const double cost0 = total(e, u, ql, L);
+        double alpha = 1.0;
+        while (true) {
+            Vec ut = u;
+            for (int i = 0; i < N; i++) ut[i] += alpha * du[i];
+            auto ft = s.fpBatch(ut);
+            const double c = total(s.diffBatch(pick(std::get<0>(ft), nf)), ut, pick(std::get<1>(ft), n), limits_of(std::get<2>(ft)));
+            if ((c < cost0) || (alpha < 1e-3)) { u = ut; break; }
+            alpha /= 2;
+        }
+        std::stringstream msg;
+        msg << "Iteration " << it + 1 << ", Cost: " << cost0 << ", alpha= " << alpha;
+        if (cb == nullptr) std::cout << msg.str() << std::endl;
+        else cb->notify(msg.str());
+        double dn = 0;
+        for (double v : du) dn += v * v;
+        if (early_stop && alpha * std::sqrt(dn) < 1e-3) break;
+    }
+    s.reset();
+    return u;
+}
 }  // namespace
+
+Vec solve_batch_over_virtuals(sys::System& s, const Mat* psi, const Mat& Q, int nb_iter, const Vec& u0, bool early_stop, CallBackMessage* cb) {
+    return batch_over_virtuals(s, psi, Q, nb_iter, u0, early_stop, cb);
+}
 
 std::tuple<std::vector<Vec>, std::vector<Vec>, std::vector<Vec>, std::vector<Mat>, std::vector<Vec>, double> solve_over_virtuals(
     sys::System& s, const std::vector<Vec>& U0, int nb_iter, bool line_search, bool early_stop, CallBackMessage* cb) {

@@ -5,6 +5,8 @@
 #include <cmath>
 #include <cstdio>
 #include <memory>
+#include <string>
+#include <vector>
 
 #include "../../ilqr_planner_amd/csrc/host/ilqr_host.hpp"
 
@@ -15,9 +17,23 @@ struct OffsetRobot : sim::KDLRobot {  // a tool 5 cm further along the base z ax
     void updateKinematics() override { sim::KDLRobot::updateKinematics(); x[2] += 0.05; }
 };
 
+struct SameRobot : sim::KDLRobot {  // a subclass that changes nothing: still taken over its virtuals (the type decides), so host and device can be compared
+    using sim::KDLRobot::KDLRobot;
+    void updateKinematics() override { sim::KDLRobot::updateKinematics(); }
+};
+
 struct Quiet : CallBackMessage {
     int n = 0;
     void notify(const std::string&) override { n++; }
+};
+
+struct Costs : CallBackMessage {  // "Iteration i, Cost: c, alpha= a"
+    std::vector<double> cost, alpha;
+    void notify(const std::string& m) override {
+        const size_t a = m.find("Cost: "), b = m.find(", alpha= ");
+        cost.push_back(std::stod(m.substr(a + 6, b - a - 6)));
+        alpha.push_back(std::stod(m.substr(b + 9)));
+    }
 };
 
 #define CHECK(cond)                                                    \
@@ -53,6 +69,36 @@ int main(int argc, char** argv) {
     CHECK(std::fabs(fa[2] - target[2]) < 5e-3 && std::fabs(fb[2] - target[2]) < 5e-3);
     sim::KDLRobot probe(argv[1], "panda_link0", "panda_tip", std::get<0>(b).back(), dq0);
     CHECK(std::fabs(probe.getEEPosition()[2] - (target[2] - 0.05)) < 5e-3);
+    // BatchILQRCP / BatchILQR: the device solve of the plain robot against the host loop over the virtuals of a subclass that changes nothing
+    {
+        auto same = make(std::make_shared<SameRobot>(argv[1], "panda_link0", "panda_tip", q0, dq0));
+        CHECK(!same->builtin());
+        const int N = 7 * (T - 1);
+        Mat P(N, 14);  // per joint: a constant and a step at half the horizon
+        for (int k = 0; k < T - 1; k++)
+            for (int i = 0; i < 7; i++) { P(7 * k + i, i) = 1.0; P(7 * k + i, 7 + i) = (k >= (T - 1) / 2) ? 1.0 : 0.0; }
+        const Vec u0(N, 0.0);
+        Costs cd, ch;
+        const Vec ud = solver::BatchILQRCP(plain, P).solve(5, u0, false, &cd);
+        const Vec uh = solver::BatchILQRCP(same, P).solve(5, u0, false, &ch);
+        CHECK(cd.cost.size() == 5 && ch.cost.size() == 5);
+        for (int i = 0; i < 5; i++) {
+            CHECK(cd.alpha[i] == ch.alpha[i]);
+            CHECK(std::fabs(cd.cost[i] - ch.cost[i]) <= 1e-5 * std::fabs(cd.cost[i]) + 1e-12);  // (printed with six significant digits)
+        }
+        double worst = 0;
+        for (int i = 0; i < N; i++) worst = std::fmax(worst, std::fabs(ud[i] - uh[i]));
+        CHECK(worst <= 1e-6);
+        Costs bd, bh;
+        const Vec vd = solver::BatchILQR(plain).solve(3, u0, false, &bd);
+        const Vec vh = solver::BatchILQR(same).solve(3, u0, false, &bh);
+        CHECK(bd.cost.size() == 3 && bh.cost.size() == 3);
+        for (int i = 0; i < 3; i++) CHECK(bd.alpha[i] == bh.alpha[i] && std::fabs(bd.cost[i] - bh.cost[i]) <= 1e-5 * std::fabs(bd.cost[i]) + 1e-12);
+        worst = 0;
+        for (int i = 0; i < N; i++) worst = std::fmax(worst, std::fabs(vd[i] - vh[i]));
+        CHECK(worst <= 1e-6);
+        std::printf("batch solvers: device and host loop agree (BatchILQRCP cost %.6g -> %.6g, BatchILQR %.6g -> %.6g)\n", cd.cost.front(), cd.cost.back(), bd.cost.front(), bd.cost.back());
+    }
     std::printf("ok: plain on the device (z %.4f), subclass over its virtuals (z %.4f, base chain %.4f)\n", fa[2], fb[2], probe.getEEPosition()[2]);
     return 0;
 }

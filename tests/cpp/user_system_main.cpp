@@ -10,6 +10,16 @@
 
 using namespace ilqr_planner;
 
+// a user-defined keypoint for the batch solvers (they look at the system through its keypoints: getKpIndexes, diffBatch, getQMatrix)
+struct PointKp : sys::Keypoint {
+    Vec target, qd;
+    PointKp(int t, const Vec& tg, const Vec& q) : sys::Keypoint(t, sys::Keypoint::SECOND_ORDER, "POINT_KP"), target(tg), qd(q) {}
+    Vec diff(const Vec& st) const override { Vec e(4); for (int i = 0; i < 4; i++) e[i] = target[i] - st[i]; return e; }
+    Vec getState() const override { return target; }
+    Mat getPrecision() const override { Mat P(4, 4); for (int i = 0; i < 4; i++) P(i, i) = qd[i]; return P; }
+    Vec targetFx() const override { return target; }
+};
+
 struct PointSys : sys::System {
     double dt;
     Vec x, xt, qdiag;
@@ -17,7 +27,7 @@ struct PointSys : sys::System {
     // resets it at the top of every iteration before cost_F_xx (:66)
     int n_fp = 0, n_cost_before_fp = 0, n_reset = 0, n_Fxx_without_reset = 0;
     bool stepped_since_cost = true, reset_since_Fxx = true, in_total = false;
-    PointSys(int T, double dt_) : sys::System(nullptr, {}, Vec{1e-2, 1e-2}, T, 2, {}), dt(dt_) {
+    PointSys(int T, double dt_, const std::vector<std::shared_ptr<sys::Keypoint>>& kps = {}) : sys::System(nullptr, kps, Vec{1e-2, 1e-2}, T, 2, {}), dt(dt_) {
         nb_state_var_ = 4; nb_ctrl_var_ = 2; nb_target_var_ = 4; nb_Q_var_ = 4;
         x0_ = Vec{0.2, -0.1, 0.0, 0.3};
         xt = Vec{1.0, 0.5, 0.0, 0.0};
@@ -165,6 +175,48 @@ int main() {
         std::printf("AL: unconstrained max u0 %.4g, bound %.4g, worst violation %.3g\n", umax, bound, worst);
         CHECK(worst < 0.05 * umax);   // the unconstrained optimum violates the bound by umax / 2; the augmented-Lagrangian solve respects it
         CHECK(s2->n_cost_before_fp == 0 && s2->n_Fxx_without_reset == 0);
+    }
+    // BatchILQR / BatchILQRCP over the virtuals (BatchILQR.cpp:111-173, BatchILQRCP.cpp:109-175): the same point mass with its goal as a user keypoint
+    {
+        auto kp = std::make_shared<PointKp>(T - 1, Vec{1.0, 0.5, 0.0, 0.0}, Vec{10, 10, 1, 1});
+        auto sb = std::make_shared<PointSys>(T, 0.1, std::vector<std::shared_ptr<sys::Keypoint>>{kp});
+        CHECK(!sb->builtin());
+        Vec u0;
+        for (auto& u : U0) u0.insert(u0.end(), u.begin(), u.end());
+        const int resets0 = sb->n_reset;
+        solver::BatchILQR bs(sb);
+        Collect cbb;
+        const Vec ub = bs.solve(6, u0, false, &cbb);
+        CHECK(cbb.n == 6 && cbb.with_time == 0);          // "Iteration i, Cost: c, alpha= a" -- no time field in the batch solvers
+        CHECK(sb->n_reset >= resets0 + 2);                 // reset() at the start and at the end of solve (:111,171)
+        CHECK((int)ub.size() == 2 * (T - 1));
+        std::vector<Vec> Ub(T - 1, Vec(2));
+        for (int k = 0; k < T - 1; k++) { Ub[k][0] = ub[2 * k]; Ub[k][1] = ub[2 * k + 1]; }
+        const double cb_final = sb->total(Ub);
+        std::printf("BatchILQR over the virtuals: cost %.6g -> %.6g (Riccati optimum %.6g)\n", c_init, cb_final, cost);
+        CHECK(cb_final < c_init * 2e-2);                   // descends (the reference's sensitivities are shifted by one control: not the exact Newton step)
+        CHECK(cb_final >= cost * (1 - 1e-9));              // ... and cannot beat the optimum of the same linear-quadratic problem
+        // the identity basis in BatchILQRCP is the same computation
+        Mat I(2 * (T - 1), 2 * (T - 1));
+        for (int i = 0; i < I.rows; i++) I(i, i) = 1.0;
+        solver::BatchILQRCP bcp(sb, I);
+        Collect cbc;
+        const Vec uc = bcp.solve(6, u0, false, &cbc);
+        CHECK(cbc.n == 6);
+        for (size_t i = 0; i < ub.size(); i++) CHECK(std::fabs(uc[i] - ub[i]) <= 1e-9 * (1 + std::fabs(ub[i])));
+        // a two-column basis per control (constant + ramp over the horizon): the solve stays in its span
+        Mat P(2 * (T - 1), 4);
+        for (int k = 0; k < T - 1; k++)
+            for (int i = 0; i < 2; i++) { P(2 * k + i, i) = 1.0; P(2 * k + i, 2 + i) = (double)k / (T - 2); }
+        solver::BatchILQRCP bcp2(sb, P);
+        const Vec u00(2 * (T - 1), 0.0);
+        const Vec u2 = bcp2.solve(5, u00, false, &cbc);
+        for (int k = 1; k + 1 < T - 1; k++)               // affine in k: second differences vanish
+            for (int i = 0; i < 2; i++) CHECK(std::fabs(u2[2 * (k + 1) + i] - 2 * u2[2 * k + i] + u2[2 * (k - 1) + i]) <= 1e-9);
+        std::vector<Vec> U2(T - 1, Vec(2));
+        for (int k = 0; k < T - 1; k++) { U2[k][0] = u2[2 * k]; U2[k][1] = u2[2 * k + 1]; }
+        std::vector<Vec> Uz(T - 1, Vec(2, 0.0));
+        CHECK(sb->total(U2) < sb->total(Uz));
     }
     std::printf("ok: cost %.6g -> %.6g in 3 iterations\n", c_init, cost);
     return 0;
