@@ -159,6 +159,25 @@ def test_forward_passes_agree(ctx, cfg_name, solver, B, monkeypatch):
     np.testing.assert_allclose(b["X"], a["X"], rtol=0, atol=1e-11)
 
 
+def test_two_stream_split_does_not_change_results(ctx, monkeypatch):
+    """Large batches on the matrix-core sweep (one instance per wave) are solved as two halves on two internal streams, the second one sweep behind
+    the first (ilqr_ctx_set_split).  Since round 3 the time systems take the row-per-lane sweep at these sizes, so the schedule is reached through the
+    cross-check switch (and by the shapes only the matrix-core sweep takes); instances are independent: bit-identical results with the split on and off."""
+    from ilqr_planner_amd import workloads
+
+    monkeypatch.setenv("ILQR_SWEEP", "mfma")
+    cfg = dict(workloads.config("C4"), T=40)
+    B, nb_iter = 2304, 3
+    desc, inp = workloads.make_batch(ctx, cfg, B=B)
+    res = {}
+    for on in (1, 0):
+        ctx.set_split(on)
+        res[on] = _solve(ctx, cfg, desc, inp, B, nb_iter, "recursive")
+    ctx.set_split(1)
+    for k in ("cost", "U", "X", "iters", "alpha"):
+        np.testing.assert_array_equal(res[1][k], res[0][k])
+
+
 @pytest.mark.parametrize("cfg_name,B", [("C4", 256), ("C4t1", 100), ("C1t", 64)])
 def test_rerolls_of_the_winner_agree(ctx, cfg_name, B, monkeypatch):
     """Time systems: the winner of the step-size-parallel line search is rolled out again where the speculated step size lost -- by k_apply_dpp_tm (16 lanes
